@@ -1,0 +1,72 @@
+// Shared internals of libsquidstitch: error reporting and the device table layout.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/squidstitch.h"
+
+namespace sq {
+
+std::string &last_error_ref();
+
+inline int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+// ---- fusion table (host builds it, device reads it) -------------------------------------
+// One plane of the canvas is cut into disjoint spans.  A span is a rectangle of the canvas
+// whose every voxel is produced from the same ordered list of tiles ("refs"): none (zero
+// fill), one (overwrite mode: the last writer), or several (feather mode).
+constexpr uint32_t TABLE_MAGIC = 0x53514654u;  // "SQFT"
+constexpr int BLOCK_ROWS = 8;                  // rows of a span one workgroup takes
+constexpr int BLOCK_COLS = 2048;               // columns of a span one workgroup takes
+constexpr int MAX_REFS = 8;                    // feather: most tiles blended in one span
+
+struct TableHeader {
+    uint32_t magic;
+    int32_t mode;
+    int32_t canvas_h, canvas_w;
+    int32_t tile_h, tile_w;
+    int32_t n_tiles, max_refs;
+    int64_t n_spans, n_refs, n_items;
+    int64_t off_spans, off_refs, off_items;  // byte offsets from the table start
+    int64_t covered_voxels;
+    int64_t reserved;
+};
+static_assert(sizeof(TableHeader) == 96, "TableHeader layout");
+
+struct Span {
+    int32_t dst_y, dst_x, h, w;
+    int32_t nref, ref0;
+    int32_t pad[2];
+};
+static_assert(sizeof(Span) == 32, "Span layout");
+
+struct Ref {
+    int32_t tile;          // index into the plane's tile table
+    int32_t src_y, src_x;  // tile pixel that lands on the span's (0, 0)
+    int32_t pad;
+};
+static_assert(sizeof(Ref) == 16, "Ref layout");
+
+struct Item {
+    int32_t span;
+    int32_t row0, col0;  // block origin inside the span
+    int32_t pad;
+};
+static_assert(sizeof(Item) == 16, "Item layout");
+
+}  // namespace sq
+
+struct sq_fuse_plan {
+    std::string table;  // TableHeader + spans + refs + items, exactly what goes to the device
+    const sq::TableHeader &header() const { return *reinterpret_cast<const sq::TableHeader *>(table.data()); }
+};

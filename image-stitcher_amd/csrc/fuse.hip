@@ -1,0 +1,349 @@
+// Fusion kernels for gfx950: tiles -> canvas planes, every canvas voxel written exactly once.
+//
+// Replaces the per-file loop of the reference (stitcher.py:652-681 -> :544-611).  The host
+// planner (plan.cpp) has already cut the canvas into disjoint spans with their owning tile(s),
+// so the device work is a batch of rectangle copies with an optional per-pixel flatfield divide
+// (overwrite mode), or a weighted mean of up to MAX_REFS tiles (feather mode).
+//
+// Roofline: HBM.  Algorithmic traffic is 2 B read + 2 B write per uint16 voxel (+ the flatfield,
+// which is re-used by every tile of a channel and lives in L2 / Infinity Cache).
+//
+// Mapping: grid = (work items, planes); one item = up to BLOCK_ROWS x BLOCK_COLS of one span;
+// each of the 4 waves takes whole rows, 64 lanes x 16 B per step, so every wave-instruction
+// stores one contiguous 1 KiB run of a canvas row.  Stores are 16-byte aligned on the canvas
+// side (the canvas pitch is arbitrary, so the alignment phase is recomputed per row); the tile
+// side is read with 16-byte loads at whatever 2-byte phase the placement leaves.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+using namespace sq;
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct __attribute__((packed)) U32x4U {  // 16 bytes at any alignment
+    u32x4 v;
+};
+struct __attribute__((packed)) F32x4U {
+    f32x4 v;
+};
+struct __attribute__((packed)) F64x2U {
+    f64x2 v;
+};
+
+#define SQ_GLOBAL __attribute__((address_space(1)))
+// Explicit global-address-space accessors: pointers that come out of a table are generic to the
+// compiler and would be lowered to flat_* instructions.
+template <typename V>
+__device__ __forceinline__ auto ldg_nt(const void *p) {  // streamed once: non-temporal
+    return __builtin_nontemporal_load(&((const SQ_GLOBAL V *)p)->v);
+}
+template <typename V>
+__device__ __forceinline__ auto ldg(const void *p) {
+    return ((const SQ_GLOBAL V *)p)->v;
+}
+template <typename S>
+__device__ __forceinline__ S ldg_s(const void *p) {
+    return *(const SQ_GLOBAL S *)p;
+}
+__device__ __forceinline__ void stg_nt(void *p, u32x4 v) { __builtin_nontemporal_store(v, (SQ_GLOBAL u32x4 *)p); }
+template <typename S>
+__device__ __forceinline__ void stg_s(void *p, S v) {
+    *(SQ_GLOBAL S *)p = v;
+}
+
+struct FuseParams {
+    const Span *spans;
+    const Ref *refs;
+    const Item *items;
+    const void *const *tile_ptrs;
+    const void *tile_base;
+    int64_t tile_plane_stride, tile_stride;
+    const void *const *flat_ptrs;
+    void *canvas;
+    int64_t canvas_plane_stride;
+    int32_t n_tiles, tile_h, tile_w, tile_pitch;
+    int32_t canvas_pitch;
+};
+
+template <typename T>
+__device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int tile) {
+    if (P.tile_ptrs) return static_cast<const T *>(P.tile_ptrs[(int64_t)plane * P.n_tiles + tile]);
+    return static_cast<const T *>(P.tile_base) + plane * P.tile_plane_stride + tile * P.tile_stride;
+}
+
+// divide -> clip -> truncating cast of apply_flatfield_correction (stitcher.py:609-610), in the
+// flatfield's own precision like numpy's uint16 / floatXX promotion.  NaN (0/0) -> 0, which is
+// what the x86 cast of the reference produces; +inf -> dtype max through the clip.
+template <typename T>
+__device__ __forceinline__ T flat_f32(T v, float g) {
+    float q = __fdiv_rn((float)v, g);
+    const float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    q = fminf(fmaxf(q, 0.0f), hi);
+    return (T)q;
+}
+template <typename T>
+__device__ __forceinline__ T flat_f64(T v, double g) {
+    double q = __ddiv_rn((double)v, g);
+    const double hi = sizeof(T) == 1 ? 255.0 : 65535.0;
+    q = fmin(fmax(q, 0.0), hi);
+    return (T)q;
+}
+
+template <typename T, int FLAT>
+__device__ __forceinline__ T correct_one(T v, const void *frow, int p) {
+    if (FLAT == 1) return flat_f32<T>(v, ldg_s<float>(static_cast<const float *>(frow) + p));
+    if (FLAT == 2) return flat_f64<T>(v, ldg_s<double>(static_cast<const double *>(frow) + p));
+    return v;
+}
+
+template <typename T>
+struct Pix;  // 16 bytes of pixels
+template <>
+struct Pix<uint16_t> {
+    static constexpr int N = 8;
+    __device__ static uint16_t get(const u32x4 &v, int e) { return (uint16_t)(v[e >> 1] >> ((e & 1) * 16)); }
+    __device__ static void set(u32x4 &v, int e, uint16_t x) {
+        v[e >> 1] = (e & 1) ? ((v[e >> 1] & 0x0000FFFFu) | ((uint32_t)x << 16)) : ((v[e >> 1] & 0xFFFF0000u) | x);
+    }
+};
+template <>
+struct Pix<uint8_t> {
+    static constexpr int N = 16;
+    __device__ static uint8_t get(const u32x4 &v, int e) { return (uint8_t)(v[e >> 2] >> ((e & 3) * 8)); }
+    __device__ static void set(u32x4 &v, int e, uint8_t x) {
+        const int sh = (e & 3) * 8;
+        v[e >> 2] = (v[e >> 2] & ~(0xFFu << sh)) | ((uint32_t)x << sh);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// overwrite mode (the reference's semantics)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int FLAT>
+__global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P) {
+    constexpr int VEC = Pix<T>::N;
+    const Item it = P.items[blockIdx.x];
+    const int plane = blockIdx.y;
+    const Span sp = P.spans[it.span];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rows = min(BLOCK_ROWS, sp.h - it.row0);
+    const int n = min(BLOCK_COLS, sp.w - it.col0);
+
+    T *canvas = static_cast<T *>(P.canvas) + plane * P.canvas_plane_stride;
+    const T *tile = nullptr;
+    const char *flat = nullptr;
+    int sy = 0, sx = 0;
+    if (sp.nref) {
+        const Ref rf = P.refs[sp.ref0];
+        tile = tile_ptr<T>(P, plane, rf.tile);
+        sy = rf.src_y + it.row0;
+        sx = rf.src_x + it.col0;
+        if (FLAT && P.flat_ptrs) flat = static_cast<const char *>(P.flat_ptrs[plane]);
+    }
+    constexpr int FSZ = FLAT == 2 ? 8 : 4;
+
+    for (int r = wave; r < rows; r += 4) {
+        T *drow = canvas + (int64_t)(sp.dst_y + it.row0 + r) * P.canvas_pitch + (sp.dst_x + it.col0);
+        const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) & (VEC - 1));
+        const int nvec = (n + mis + VEC - 1) / VEC;
+        if (!tile) {  // uncovered canvas: zeros (da.zeros, stitcher.py:362)
+            for (int v = lane; v < nvec; v += 64) {
+                const int p0 = v * VEC - mis;
+                if (p0 >= 0 && p0 + VEC <= n) {
+                    stg_nt(drow + p0, u32x4{0, 0, 0, 0});
+                } else {
+                    for (int e = 0; e < VEC; ++e)
+                        if (p0 + e >= 0 && p0 + e < n) stg_s<T>(drow + p0 + e, 0);
+                }
+            }
+            continue;
+        }
+        const T *srow = tile + (int64_t)(sy + r) * P.tile_pitch + sx;
+        const char *frow = (FLAT && flat) ? flat + ((int64_t)(sy + r) * P.tile_w + sx) * FSZ : nullptr;
+        for (int v = lane; v < nvec; v += 64) {
+            const int p0 = v * VEC - mis;
+            if (p0 >= 0 && p0 + VEC <= n) {
+                u32x4 px = ldg_nt<U32x4U>(srow + p0);
+                if (FLAT == 1 && frow) {
+                    const float *f = reinterpret_cast<const float *>(frow) + p0;
+#pragma unroll
+                    for (int q = 0; q < VEC / 4; ++q) {
+                        const f32x4 g = ldg<F32x4U>(f + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), g[e]));
+                    }
+                } else if (FLAT == 2 && frow) {
+                    const double *f = reinterpret_cast<const double *>(frow) + p0;
+#pragma unroll
+                    for (int q = 0; q < VEC / 2; ++q) {
+                        const f64x2 g = ldg<F64x2U>(f + 2 * q);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), g[e]));
+                    }
+                }
+                stg_nt(drow + p0, px);
+            } else {
+                for (int e = 0; e < VEC; ++e) {
+                    const int p = p0 + e;
+                    if (p >= 0 && p < n) {
+                        const T t = ldg_s<T>(srow + p);
+                        stg_s<T>(drow + p, frow ? correct_one<T, FLAT>(t, frow, p) : t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// feather mode (extension; definition = oracle/stitch_oracle.py fuse_plane_feather)
+//   out = sum_i w_i v_i / sum_i w_i, float32, tiles in write order,
+//   w_i = min(sx+1, W-sx, sy+1, H-sy) in the tile's own coordinates,
+//   v_i = tile / float32(flatfield) when a flatfield is given (no clip).
+// Compiled with -ffp-contract=off: multiply and add stay separate like numpy's.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename OutT, int FLAT>
+__global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P) {
+    const Item it = P.items[blockIdx.x];
+    const int plane = blockIdx.y;
+    const Span sp = P.spans[it.span];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rows = min(BLOCK_ROWS, sp.h - it.row0);
+    const int n = min(BLOCK_COLS, sp.w - it.col0);
+    OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
+    const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+    constexpr int FSZ = FLAT == 2 ? 8 : 4;
+    const int nref = sp.nref;
+
+    for (int r = wave; r < rows; r += 4) {
+        OutT *drow = canvas + (int64_t)(sp.dst_y + it.row0 + r) * P.canvas_pitch + (sp.dst_x + it.col0);
+        for (int p = lane; p < n; p += 64) {
+            float acc = 0.0f, wsum = 0.0f;
+            for (int k = 0; k < nref; ++k) {
+                const Ref rf = P.refs[sp.ref0 + k];
+                const T *tile = tile_ptr<T>(P, plane, rf.tile);
+                const int y = rf.src_y + it.row0 + r;
+                const int x = rf.src_x + it.col0 + p;
+                float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
+                if (FLAT && flat) {
+                    const char *g = flat + ((int64_t)y * P.tile_w + x) * FSZ;
+                    const float gf = FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g);
+                    v = __fdiv_rn(v, gf);
+                }
+                const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
+                acc = __fadd_rn(acc, __fmul_rn(w, v));
+                wsum = __fadd_rn(wsum, w);
+            }
+            float o = wsum > 0.0f ? __fdiv_rn(acc, wsum) : 0.0f;
+            if (sizeof(OutT) == 4) {
+                stg_s<float>(reinterpret_cast<float *>(drow) + p, o);
+            } else {
+                const float hi = sizeof(OutT) == 1 ? 255.0f : 65535.0f;
+                o = fminf(fmaxf(rintf(o), 0.0f), hi);
+                stg_s<OutT>(drow + p, (OutT)o);
+            }
+        }
+    }
+}
+
+template <typename K>
+int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream) {
+    if (n_items == 0 || n_planes == 0) return SQ_OK;
+    dim3 grid((unsigned)n_items, (unsigned)n_planes, 1);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_planes: launch failed: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+}  // namespace
+
+extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
+    if (!a || !a->plan || !a->table_dev || !a->canvas_dev)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: NULL plan/table/canvas");
+    const TableHeader &h = a->plan->header();
+    if (a->table_bytes != (int64_t)a->plan->table.size())
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: table_bytes %lld != plan %zu", (long long)a->table_bytes,
+                    a->plan->table.size());
+    if (a->mode != h.mode) return fail(SQ_ERR_INVALID, "sq_fuse_planes: mode %d but plan was built for %d", a->mode, h.mode);
+    if (a->n_tiles != h.n_tiles || a->tile_h != h.tile_h || a->tile_w != h.tile_w || a->canvas_h != h.canvas_h ||
+        a->canvas_w != h.canvas_w)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: geometry differs from the plan (tiles %d/%d %dx%d/%dx%d canvas %dx%d/%dx%d)",
+                    a->n_tiles, h.n_tiles, a->tile_h, a->tile_w, h.tile_h, h.tile_w, a->canvas_h, a->canvas_w, h.canvas_h,
+                    h.canvas_w);
+    if (!a->tile_ptrs_dev && !a->tile_base_dev && h.n_refs > 0)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: no tile table and no tile base");
+    if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
+    if (a->n_planes < 0 || a->n_planes > 65535) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
+    if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_fuse_planes: tile dtype %d (uint8/uint16 only)", a->tile_dtype);
+    if (a->flat_ptrs_dev && a->flat_dtype != SQ_F32 && a->flat_dtype != SQ_F64)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_fuse_planes: flatfield dtype %d (float32/float64 only)", a->flat_dtype);
+    if (a->canvas_plane_stride < (int64_t)a->canvas_h * a->canvas_pitch && a->n_planes > 1)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: canvas planes overlap");
+    const size_t esz = a->canvas_dtype == SQ_F32 ? 4 : (size_t)a->canvas_dtype;
+    if (reinterpret_cast<uintptr_t>(a->canvas_dev) % esz)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: canvas pointer not aligned to its element size");
+
+    FuseParams P{};
+    const char *base = static_cast<const char *>(a->table_dev);
+    P.spans = reinterpret_cast<const Span *>(base + h.off_spans);
+    P.refs = reinterpret_cast<const Ref *>(base + h.off_refs);
+    P.items = reinterpret_cast<const Item *>(base + h.off_items);
+    P.tile_ptrs = a->tile_ptrs_dev;
+    P.tile_base = a->tile_base_dev;
+    P.tile_plane_stride = a->tile_plane_stride;
+    P.tile_stride = a->tile_stride;
+    P.flat_ptrs = a->flat_ptrs_dev;
+    P.canvas = a->canvas_dev;
+    P.canvas_plane_stride = a->canvas_plane_stride;
+    P.n_tiles = a->n_tiles;
+    P.tile_h = a->tile_h;
+    P.tile_w = a->tile_w;
+    P.tile_pitch = a->tile_pitch;
+    P.canvas_pitch = a->canvas_pitch;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
+    const bool u16 = a->tile_dtype == SQ_U16;
+
+    if (a->mode == SQ_FUSE_OVERWRITE) {
+        if (a->canvas_dtype != a->tile_dtype)
+            return fail(SQ_ERR_INVALID, "sq_fuse_planes: overwrite mode keeps the tile dtype (canvas %d, tile %d)",
+                        a->canvas_dtype, a->tile_dtype);
+        if (u16) {
+            if (flat == 0) return launch(fuse_overwrite_kernel<uint16_t, 0>, P, h.n_items, a->n_planes, stream);
+            if (flat == 1) return launch(fuse_overwrite_kernel<uint16_t, 1>, P, h.n_items, a->n_planes, stream);
+            return launch(fuse_overwrite_kernel<uint16_t, 2>, P, h.n_items, a->n_planes, stream);
+        }
+        if (flat == 0) return launch(fuse_overwrite_kernel<uint8_t, 0>, P, h.n_items, a->n_planes, stream);
+        if (flat == 1) return launch(fuse_overwrite_kernel<uint8_t, 1>, P, h.n_items, a->n_planes, stream);
+        return launch(fuse_overwrite_kernel<uint8_t, 2>, P, h.n_items, a->n_planes, stream);
+    }
+    // feather
+    const bool f32out = a->canvas_dtype == SQ_F32;
+    if (!f32out && a->canvas_dtype != a->tile_dtype)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: feather canvas must be float32 or the tile dtype");
+#define SQ_FEATHER(T, O)                                                                             \
+    do {                                                                                             \
+        if (flat == 0) return launch(fuse_feather_kernel<T, O, 0>, P, h.n_items, a->n_planes, stream); \
+        if (flat == 1) return launch(fuse_feather_kernel<T, O, 1>, P, h.n_items, a->n_planes, stream); \
+        return launch(fuse_feather_kernel<T, O, 2>, P, h.n_items, a->n_planes, stream);               \
+    } while (0)
+    if (u16) {
+        if (f32out) SQ_FEATHER(uint16_t, float);
+        SQ_FEATHER(uint16_t, uint16_t);
+    }
+    if (f32out) SQ_FEATHER(uint8_t, float);
+    SQ_FEATHER(uint8_t, uint8_t);
+#undef SQ_FEATHER
+}

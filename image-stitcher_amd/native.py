@@ -1,0 +1,326 @@
+"""ctypes binding of libsquidstitch.so (include/squidstitch.h) -- the only way the host
+reaches the device kernels.  PyTorch-ROCm tensors are used purely as device-buffer
+containers: ``tensor.data_ptr()`` in, nothing torch-typed crosses the C-ABI.
+
+There is no CPU fallback: if the shared object is missing or a call fails, this
+module raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C image-stitcher_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsquidstitch.so')
+
+SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
+SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
+SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
+
+RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
+                       ('dst_y', '<i4'), ('dst_x', '<i4')])
+PAIR_DTYPE = np.dtype([('ref_tile', '<i4'), ('mov_tile', '<i4'), ('ref_y0', '<i4'), ('ref_x0', '<i4'),
+                       ('mov_y0', '<i4'), ('mov_x0', '<i4')])
+RESULT_DTYPE = np.dtype([('coarse', '<i4', (2,)), ('fine', '<i4', (2,)), ('ccmax_re', '<f8'),
+                         ('ccmax_im', '<f8'), ('src_amp', '<f8'), ('tgt_amp', '<f8')])
+SYNTH_DTYPE = np.dtype([('scene_seed', '<u8'), ('noise_seed', '<u8'), ('oy', '<i8'), ('ox', '<i8')])
+
+
+class NativeError(RuntimeError):
+    """A libsquidstitch call returned a negative status."""
+
+
+class _FuseArgs(C.Structure):
+    _fields_ = [
+        ('plan', C.c_void_p), ('table_dev', C.c_void_p), ('table_bytes', C.c_int64),
+        ('tile_ptrs_dev', C.c_void_p), ('tile_base_dev', C.c_void_p),
+        ('tile_plane_stride', C.c_int64), ('tile_stride', C.c_int64),
+        ('n_tiles', C.c_int32), ('tile_h', C.c_int32), ('tile_w', C.c_int32),
+        ('tile_pitch', C.c_int32), ('tile_dtype', C.c_int32),
+        ('flat_ptrs_dev', C.c_void_p), ('flat_dtype', C.c_int32),
+        ('canvas_dev', C.c_void_p), ('canvas_plane_stride', C.c_int64),
+        ('canvas_h', C.c_int32), ('canvas_w', C.c_int32), ('canvas_pitch', C.c_int32),
+        ('canvas_dtype', C.c_int32), ('n_planes', C.c_int32), ('mode', C.c_int32),
+    ]
+
+
+class _RegisterArgs(C.Structure):
+    _fields_ = [
+        ('tile_ptrs_dev', C.c_void_p), ('tile_base_dev', C.c_void_p), ('tile_stride', C.c_int64),
+        ('n_tiles', C.c_int32), ('tile_h', C.c_int32), ('tile_w', C.c_int32),
+        ('tile_pitch', C.c_int32), ('tile_dtype', C.c_int32),
+        ('minmax_dev', C.c_void_p), ('pairs_dev', C.c_void_p), ('n_pairs', C.c_int32),
+        ('n0', C.c_int32), ('n1', C.c_int32), ('upsample_factor', C.c_int32), ('normalization', C.c_int32),
+        ('results_dev', C.c_void_p), ('workspace_dev', C.c_void_p), ('workspace_bytes', C.c_int64),
+    ]
+
+
+EXPORTS = {
+    'sq_version': (C.c_int, []),
+    'sq_last_error': (C.c_char_p, []),
+    'sq_fuse_plan_create': (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'sq_fuse_plan_destroy': (None, [C.c_void_p]),
+    'sq_fuse_plan_table_bytes': (C.c_int64, [C.c_void_p]),
+    'sq_fuse_plan_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'sq_fuse_plan_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'sq_fuse_planes': (C.c_int, [C.POINTER(_FuseArgs), C.c_void_p]),
+    'sq_tile_minmax': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_void_p, C.c_void_p]),
+    'sq_register_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
+    'sq_synth_tiles': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libsquidstitch.so once; fail loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(status: int, what: str) -> None:
+    if status < 0:
+        raise NativeError(f"{what} failed ({status}): {lib().sq_last_error().decode()}")
+
+
+def sq_dtype_of(np_dtype) -> int:
+    dt = np.dtype(np_dtype)
+    table = {np.dtype('uint8'): SQ_U8, np.dtype('uint16'): SQ_U16, np.dtype('float32'): SQ_F32,
+             np.dtype('float64'): SQ_F64}
+    if dt not in table:
+        raise ValueError(f"unsupported dtype {dt} (uint8/uint16 tiles, float32/float64 gains)")
+    return table[dt]
+
+
+def torch_dtype_of(np_dtype):
+    import torch
+    return {np.dtype('uint8'): torch.uint8, np.dtype('uint16'): torch.uint16,
+            np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64}[np.dtype(np_dtype)]
+
+
+def np_dtype_of_torch(t) -> np.dtype:
+    import torch
+    return {torch.uint8: np.dtype('uint8'), torch.uint16: np.dtype('uint16'),
+            torch.float32: np.dtype('float32'), torch.float64: np.dtype('float64')}[t]
+
+
+def _stream_ptr(stream=None) -> int:
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return int(s.cuda_stream)
+
+
+def as_rects(rects) -> np.ndarray:
+    """[n, 6] ints (src_y0, src_x0, h, w, dst_y, dst_x) or a RECT_DTYPE array -> RECT_DTYPE."""
+    if isinstance(rects, np.ndarray) and rects.dtype == RECT_DTYPE:
+        return np.ascontiguousarray(rects)
+    a = np.asarray(rects, dtype=np.int64).reshape(-1, 6)
+    if a.size and (np.abs(a) >= 2 ** 31).any():
+        raise ValueError("rectangle coordinate does not fit int32")
+    out = np.zeros(len(a), dtype=RECT_DTYPE)
+    for i, name in enumerate(RECT_DTYPE.names):
+        out[name] = a[:, i]
+    return out
+
+
+class FusePlan:
+    """Host handle of one fusion plan (sq_fuse_plan_*).  ``table`` is the byte image the
+    device reads; ``device_table(device)`` uploads it once and caches the tensor."""
+
+    def __init__(self, rects, tile_h: int, tile_w: int, canvas_h: int, canvas_w: int, mode: int = SQ_FUSE_OVERWRITE):
+        L = lib()
+        self.rects = as_rects(rects)
+        self.tile_h, self.tile_w = int(tile_h), int(tile_w)
+        self.canvas_h, self.canvas_w = int(canvas_h), int(canvas_w)
+        self.mode = int(mode)
+        self.n_tiles = len(self.rects)
+        self._h = L.sq_fuse_plan_create(self.rects.ctypes.data if self.n_tiles else None, self.n_tiles,
+                                        self.tile_h, self.tile_w, self.canvas_h, self.canvas_w, self.mode)
+        if not self._h:
+            raise NativeError(f"sq_fuse_plan_create failed: {L.sq_last_error().decode()}")
+        nbytes = L.sq_fuse_plan_table_bytes(self._h)
+        self.table = np.empty(nbytes, dtype=np.uint8)
+        _check(L.sq_fuse_plan_export(self._h, self.table.ctypes.data, nbytes), 'sq_fuse_plan_export')
+        ns, ni, cv, mr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _check(L.sq_fuse_plan_stats(self._h, C.byref(ns), C.byref(ni), C.byref(cv), C.byref(mr)), 'sq_fuse_plan_stats')
+        self.n_spans, self.n_items, self.covered_voxels, self.max_refs = ns.value, ni.value, cv.value, mr.value
+        self._dev = {}
+
+    @property
+    def handle(self) -> int:
+        return self._h
+
+    def device_table(self, device):
+        import torch
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.table).to(device)
+        return self._dev[key]
+
+    def close(self) -> None:
+        if getattr(self, '_h', None):
+            lib().sq_fuse_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pointer_table(tensors: Sequence, device):
+    """Device int64 tensor of data_ptr()s (0 for None); the caller keeps ``tensors`` alive."""
+    import torch
+    ptrs = [0 if t is None else int(t.data_ptr()) for t in tensors]
+    return torch.tensor(ptrs, dtype=torch.int64).to(device)
+
+
+def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, stream=None) -> None:
+    """Fuse all planes of ``canvas`` ([P, Hc, Wc] or [..., Hc, Wc] contiguous) from ``tiles``.
+
+    tiles:     contiguous device tensor [P, N, H, W] (N = plan.n_tiles), or None with
+               ``tile_ptrs`` = device int64 tensor [P*N] of tile pointers (dense H x W tiles).
+    flats:     None, or a list of P device tensors / None (H x W float32 or float64 gains);
+               all non-None entries must share one dtype.
+    """
+    import torch
+    L = lib()
+    if not canvas.is_cuda or not canvas.is_contiguous():
+        raise ValueError("canvas must be a contiguous device tensor")
+    hc, wc = int(canvas.shape[-2]), int(canvas.shape[-1])
+    n_planes = int(canvas.numel() // (hc * wc)) if hc * wc else 0
+    a = _FuseArgs()
+    a.plan = plan.handle
+    table = plan.device_table(canvas.device)
+    a.table_dev = table.data_ptr()
+    a.table_bytes = table.numel()
+    keep = [table]
+    if tile_ptrs is not None:
+        if tile_ptrs.dtype != torch.int64 or tile_ptrs.numel() != n_planes * plan.n_tiles:
+            raise ValueError("tile_ptrs must be int64 with n_planes * n_tiles entries")
+        a.tile_ptrs_dev = tile_ptrs.data_ptr()
+        a.tile_base_dev = None
+        tile_np = np_dtype_of_torch(canvas.dtype) if plan.mode == SQ_FUSE_OVERWRITE else np.dtype('uint16')
+        if tiles is not None:
+            tile_np = np_dtype_of_torch(tiles.dtype)
+    else:
+        if tiles is None or not tiles.is_cuda or not tiles.is_contiguous():
+            raise ValueError("tiles must be a contiguous device tensor")
+        if tiles.numel() != n_planes * plan.n_tiles * plan.tile_h * plan.tile_w:
+            raise ValueError(f"tiles has {tiles.numel()} elements, expected "
+                             f"{n_planes}x{plan.n_tiles}x{plan.tile_h}x{plan.tile_w}")
+        a.tile_ptrs_dev = None
+        a.tile_base_dev = tiles.data_ptr()
+        a.tile_stride = plan.tile_h * plan.tile_w
+        a.tile_plane_stride = plan.n_tiles * plan.tile_h * plan.tile_w
+        tile_np = np_dtype_of_torch(tiles.dtype)
+    a.n_tiles, a.tile_h, a.tile_w, a.tile_pitch = plan.n_tiles, plan.tile_h, plan.tile_w, plan.tile_w
+    a.tile_dtype = sq_dtype_of(tile_np)
+    a.flat_ptrs_dev = None
+    a.flat_dtype = SQ_F32
+    if flats is not None and any(f is not None for f in flats):
+        if len(flats) != n_planes:
+            raise ValueError("flats needs one entry per plane")
+        dts = {f.dtype for f in flats if f is not None}
+        if len(dts) != 1:
+            raise ValueError("all flatfields must share one dtype")
+        for f in flats:
+            if f is not None and (tuple(f.shape) != (plan.tile_h, plan.tile_w) or not f.is_contiguous()):
+                raise ValueError("flatfield must be a contiguous tile_h x tile_w tensor")
+        a.flat_dtype = sq_dtype_of(np_dtype_of_torch(dts.pop()))
+        fp = pointer_table(flats, canvas.device)
+        keep.append(fp)
+        a.flat_ptrs_dev = fp.data_ptr()
+    a.canvas_dev = canvas.data_ptr()
+    a.canvas_plane_stride = hc * wc
+    a.canvas_h, a.canvas_w, a.canvas_pitch = hc, wc, wc
+    a.canvas_dtype = sq_dtype_of(np_dtype_of_torch(canvas.dtype))
+    a.n_planes = n_planes
+    a.mode = plan.mode
+    _check(L.sq_fuse_planes(C.byref(a), _stream_ptr(stream)), 'sq_fuse_planes')
+
+
+def tile_minmax(tiles, stream=None):
+    """Per-tile (min, max) of a contiguous device stack [N, H, W] -> device int32 tensor [N, 2]
+    (values are uint32 on the C side; they fit int32 for uint8/uint16 tiles)."""
+    import torch
+    L = lib()
+    n, h, w = (int(v) for v in tiles.shape)
+    out = torch.empty((n, 2), dtype=torch.int32, device=tiles.device)
+    _check(L.sq_tile_minmax(None, tiles.data_ptr(), h * w, n, h, w, w,
+                            sq_dtype_of(np_dtype_of_torch(tiles.dtype)), out.data_ptr(), _stream_ptr(stream)),
+           'sq_tile_minmax')
+    return out
+
+
+def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
+                   normalization: int = SQ_NORM_PHASE, stream=None) -> np.ndarray:
+    """Batched phase cross-correlation of crop pairs.  ``tiles`` [N, H, W] device stack,
+    ``pairs`` PAIR_DTYPE host array.  Returns a RESULT_DTYPE host array (synchronises)."""
+    import torch
+    L = lib()
+    n, h, w = (int(v) for v in tiles.shape)
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    npairs = len(pairs)
+    out = np.zeros(npairs, dtype=RESULT_DTYPE)
+    if npairs == 0:
+        return out
+    ws_bytes = L.sq_register_workspace_bytes(npairs, n0, n1, upsample_factor)
+    if ws_bytes < 0:
+        raise NativeError(f"sq_register_workspace_bytes failed: {L.sq_last_error().decode()}")
+    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=tiles.device)
+    pairs_dev = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(tiles.device)
+    res_dev = torch.zeros(npairs * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=tiles.device)
+    a = _RegisterArgs()
+    a.tile_ptrs_dev = None
+    a.tile_base_dev = tiles.data_ptr()
+    a.tile_stride = h * w
+    a.n_tiles, a.tile_h, a.tile_w, a.tile_pitch = n, h, w, w
+    a.tile_dtype = sq_dtype_of(np_dtype_of_torch(tiles.dtype))
+    a.minmax_dev = minmax.data_ptr()
+    a.pairs_dev = pairs_dev.data_ptr()
+    a.n_pairs = npairs
+    a.n0, a.n1 = int(n0), int(n1)
+    a.upsample_factor = int(upsample_factor)
+    a.normalization = int(normalization)
+    a.results_dev = res_dev.data_ptr()
+    a.workspace_dev = ws.data_ptr()
+    a.workspace_bytes = ws.numel()
+    _check(L.sq_register_pairs(C.byref(a), _stream_ptr(stream)), 'sq_register_pairs')
+    return res_dev.cpu().numpy().view(RESULT_DTYPE).copy()
+
+
+def synth_tiles(desc: np.ndarray, tile_h: int, tile_w: int, noise_amp: int, np_dtype, device, out=None, stream=None):
+    """Generate tiles on the device from SYNTH_DTYPE descriptors -> [n, H, W] tensor."""
+    import torch
+    L = lib()
+    desc = np.ascontiguousarray(desc, dtype=SYNTH_DTYPE)
+    n = len(desc)
+    if out is None:
+        out = torch.empty((n, tile_h, tile_w), dtype=torch_dtype_of(np_dtype), device=device)
+    d = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(device)
+    for i0 in range(0, n, 32768):   # grid.z limit
+        i1 = min(n, i0 + 32768)
+        _check(L.sq_synth_tiles(d.data_ptr() + i0 * SYNTH_DTYPE.itemsize, i1 - i0, tile_h, tile_w, noise_amp,
+                                sq_dtype_of(np_dtype), out[i0:].data_ptr(), _stream_ptr(stream)), 'sq_synth_tiles')
+    return out

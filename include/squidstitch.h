@@ -1,0 +1,185 @@
+/*
+ * libsquidstitch -- C-ABI of the MI355X (gfx950) registration-and-fusion core.
+ *
+ * The reference (sohamazing/image-stitcher) has no FFI: its hot path is Python methods of
+ * `Stitcher` (stitcher.py:31).  Each entry point below replaces the arithmetic inside one or
+ * more of those methods; the integer geometry stays on the host, written exactly as the
+ * reference writes it, and only rectangles / crop origins cross this boundary.
+ *
+ * Conventions
+ *  - `extern "C"`, plain C types.  No torch types, no C++ types.
+ *  - Every `*_dev` pointer is a DEVICE pointer owned by the caller (e.g. a PyTorch-ROCm
+ *    tensor's data_ptr()).  The library never allocates, frees or keeps caller memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All device work
+ *    is enqueued on it and is asynchronous; no entry point synchronises.
+ *  - Return value: 0 = OK, negative = sq_status.  sq_last_error() gives the thread-local
+ *    message of the last failure on the calling thread.
+ *  - No global mutable state: handles are immutable after creation; safe to use from a
+ *    QThread or a multiprocessing child as the reference's front-ends do.
+ */
+#ifndef SQUIDSTITCH_H
+#define SQUIDSTITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_VERSION 100 /* 0.1.0 */
+
+typedef enum sq_status {
+    SQ_OK = 0,
+    SQ_ERR_INVALID = -1,     /* bad argument (NULL, negative size, unknown enum, misaligned) */
+    SQ_ERR_HIP = -2,         /* a HIP runtime call or launch failed                          */
+    SQ_ERR_UNSUPPORTED = -3, /* valid request this build cannot serve                        */
+    SQ_ERR_WORKSPACE = -4    /* caller workspace too small                                   */
+} sq_status;
+
+typedef enum sq_dtype { SQ_U8 = 1, SQ_U16 = 2, SQ_F32 = 4, SQ_F64 = 8 } sq_dtype;
+
+int sq_version(void);
+const char *sq_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Fusion: replaces the per-file loop of Stitcher.stitch_region (stitcher.py:652-681) together
+ * with place_tile / place_single_channel_tile (:544-605) and apply_flatfield_correction
+ * (:607-611), for all (channel, z) planes of one (timepoint, region) in one launch.
+ * ---------------------------------------------------------------------------------------- */
+
+/* One tile's rectangle after the reference's crop (stitcher.py:577-587), BEFORE the canvas
+ * clip of :590-594 (the library applies that clip).  Array order = the reference's write
+ * order (sorted-filename order within a plane, stitcher.py:168,652): a later rect overwrites
+ * an earlier one where they overlap. */
+typedef struct sq_rect {
+    int32_t src_y0, src_x0; /* first tile pixel used (top_crop, left_crop)              */
+    int32_t h, w;           /* size of the cropped tile                                 */
+    int32_t dst_y, dst_x;   /* canvas position of that first pixel (y_pixel, x_pixel)   */
+} sq_rect;
+
+typedef enum sq_fuse_mode {
+    SQ_FUSE_OVERWRITE = 0, /* the reference: last writer wins, output dtype = tile dtype   */
+    SQ_FUSE_FEATHER = 1    /* extension: distance-to-edge weighted mean of all covering tiles */
+} sq_fuse_mode;
+
+/* Opaque host-side plan: the canvas of one plane cut into disjoint spans, each with the
+ * tile(s) that own it, plus the launch work-list.  Depends only on integer geometry, so one
+ * plan serves every (c, z) plane of a region, every timepoint and every region that share
+ * shifts (the reference computes shifts once per run, stitcher.py:1244-1246). */
+typedef struct sq_fuse_plan sq_fuse_plan;
+
+/* Build a plan.  Returns NULL on error (see sq_last_error).
+ * tile_h/tile_w: full tile size (needed for feather weights and bounds checks). */
+sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+                                  int32_t canvas_h, int32_t canvas_w, int32_t mode);
+void sq_fuse_plan_destroy(sq_fuse_plan *plan);
+/* Size of the device table and a copy of it into caller host memory; the caller uploads it
+ * (e.g. torch.from_numpy(...).cuda()) and passes the device copy to sq_fuse_planes. */
+int64_t sq_fuse_plan_table_bytes(const sq_fuse_plan *plan);
+int sq_fuse_plan_export(const sq_fuse_plan *plan, void *host_buf, int64_t host_bytes);
+/* Introspection (tests, DESIGN.md numbers): n_spans, n_items, covered voxels, max tiles/span. */
+int sq_fuse_plan_stats(const sq_fuse_plan *plan, int64_t *n_spans, int64_t *n_items, int64_t *covered_voxels,
+                       int32_t *max_refs);
+
+typedef struct sq_fuse_args {
+    /* plan */
+    const sq_fuse_plan *plan; /* host handle (sizes, launch geometry)                       */
+    const void *table_dev;    /* device copy of sq_fuse_plan_export()                       */
+    int64_t table_bytes;
+    /* tiles: either a device array of n_planes*n_tiles device pointers (plane-major), or    */
+    /* tile_base_dev + (plane*plane_stride + tile*tile_stride) elements when tile_ptrs_dev==0 */
+    const void *const *tile_ptrs_dev;
+    const void *tile_base_dev;
+    int64_t tile_plane_stride, tile_stride; /* in elements                                   */
+    int32_t n_tiles, tile_h, tile_w;
+    int32_t tile_pitch;                     /* elements between tile rows (>= tile_w)        */
+    int32_t tile_dtype;                     /* SQ_U8 | SQ_U16                                */
+    /* flatfield (apply_flatfield_correction): device array of n_planes device pointers to   */
+    /* tile_h x tile_w gains, NULL array or NULL entry = identity for that plane             */
+    const void *const *flat_ptrs_dev;
+    int32_t flat_dtype; /* SQ_F32 | SQ_F64: decides the division precision like numpy     */
+    /* canvas */
+    void *canvas_dev;            /* plane p at canvas_dev + p*canvas_plane_stride elements */
+    int64_t canvas_plane_stride; /* elements                                               */
+    int32_t canvas_h, canvas_w, canvas_pitch;
+    int32_t canvas_dtype; /* overwrite: == tile_dtype; feather: tile_dtype or SQ_F32       */
+    int32_t n_planes;
+    int32_t mode; /* must match the plan                                               */
+} sq_fuse_args;
+
+/* Fuse n_planes planes.  Every canvas voxel is written exactly once (uncovered voxels = 0,
+ * the reference starts from da.zeros, stitcher.py:362); no atomics; deterministic. */
+int sq_fuse_planes(const sq_fuse_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Registration: replaces normalize_image (stitcher.py:613-617), the crops of
+ * calculate_horizontal_shift / calculate_vertical_shift (:504-506, :517-519) and
+ * skimage.registration.phase_cross_correlation(upsample_factor=10) (:510, :523), batched
+ * over tile pairs.  The python round() and the "- crop width" of :511/:524 stay on the host.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Per-tile min and max (normalize_image's reductions): out_minmax_dev[2*i] = min,
+ * [2*i+1] = max as uint32, for n_tiles tiles given by pointer table or base+stride. */
+int sq_tile_minmax(const void *const *tile_ptrs_dev, const void *tile_base_dev, int64_t tile_stride, int32_t n_tiles,
+                   int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype,
+                   uint32_t *out_minmax_dev, void *stream);
+
+typedef enum sq_normalization {
+    SQ_NORM_NONE = 0, /* scikit-image <= 0.18                                       */
+    SQ_NORM_PHASE = 1 /* scikit-image >= 0.19 default: P /= max(|P|, 100 eps)       */
+} sq_normalization;
+
+/* One pair: crop origin inside the reference tile and inside the moving tile; both crops are
+ * n0 x n1 (shared by the whole batch). */
+typedef struct sq_pair {
+    int32_t ref_tile, mov_tile; /* indices into the tile table / minmax table          */
+    int32_t ref_y0, ref_x0;     /* crop origin in the reference tile                   */
+    int32_t mov_y0, mov_x0;     /* crop origin in the moving tile                      */
+} sq_pair;
+
+/* Result per pair.  shift = round(coarse*u)/u + (fine - fix(ceil(1.5u)/2))/u is formed on the
+ * host in float64 exactly as skimage does (_phase_cross_correlation.py:232-250). */
+typedef struct sq_pair_result {
+    int32_t coarse[2]; /* whole-pixel peak after wrap-around (skimage :215-220)        */
+    int32_t fine[2];   /* argmax index in the 15x15 upsampled neighbourhood (:244)     */
+    double ccmax_re, ccmax_im; /* cross-correlation value at the refined peak          */
+    double src_amp, tgt_amp;   /* sum |F|^2, sum |G|^2 (:252-254)                      */
+} sq_pair_result;
+
+typedef struct sq_register_args {
+    const void *const *tile_ptrs_dev; /* or NULL + base/stride                          */
+    const void *tile_base_dev;
+    int64_t tile_stride;
+    int32_t n_tiles, tile_h, tile_w, tile_pitch, tile_dtype;
+    const uint32_t *minmax_dev; /* from sq_tile_minmax (2 per tile)                     */
+    const sq_pair *pairs_dev;
+    int32_t n_pairs;
+    int32_t n0, n1; /* crop size (rows, cols)                                           */
+    int32_t upsample_factor; /* 10 in the reference; >= 1                                */
+    int32_t normalization;   /* sq_normalization                                         */
+    sq_pair_result *results_dev;
+    void *workspace_dev;
+    int64_t workspace_bytes;
+} sq_register_args;
+
+/* Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
+int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
+int sq_register_pairs(const sq_register_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic tiles on the device (bench / tests only): the generator of
+ * image-stitcher_amd/synth.py, bit for bit.  out_dev[i] is tile i (tile_h x tile_w, dense).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sq_synth_tile {
+    uint64_t scene_seed, noise_seed;
+    int64_t oy, ox; /* scene origin of the tile */
+} sq_synth_tile;
+
+int sq_synth_tiles(const sq_synth_tile *tiles_dev, int32_t n_tiles, int32_t tile_h, int32_t tile_w, int32_t noise_amp,
+                   int32_t tile_dtype, void *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQUIDSTITCH_H */

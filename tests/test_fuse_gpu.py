@@ -1,0 +1,173 @@
+"""Parity of the HIP fusion kernels (through the C-ABI) against the oracle.  Bit-exact for
+overwrite mode (uint16/uint8, with and without flatfield); feather mode is an extension and
+is held to 1e-5 relative against the oracle's definition."""
+import numpy as np
+import pytest
+
+from helpers import REGION_CASES  # noqa: F401  (keeps helpers importable on the GPU box)
+from image_stitcher_amd import native, synth
+from oracle import stitch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+def run_fuse(rects, tiles_np, ch, cw, mode=native.SQ_FUSE_OVERWRITE, flats_np=None, out_dtype=None, use_ptrs=False,
+             n_planes=1):
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    th, tw = tiles_np.shape[-2:]
+    plan = native.FusePlan(rects, th, tw, ch, cw, mode)
+    tiles = torch.from_numpy(np.ascontiguousarray(tiles_np)).to(dev)
+    out_dtype = out_dtype or tiles_np.dtype
+    canvas = torch.full((n_planes, ch, cw), 7, dtype=native.torch_dtype_of(out_dtype), device=dev)
+    flats = None
+    if flats_np is not None:
+        flats = [None if f is None else torch.from_numpy(f).to(dev) for f in flats_np]
+    if use_ptrs:
+        flat_list = tiles.reshape(-1, th, tw)
+        ptrs = native.pointer_table([flat_list[i] for i in range(flat_list.shape[0])], dev)
+        native.fuse_planes(plan, None if mode == native.SQ_FUSE_OVERWRITE else tiles, canvas, flats, tile_ptrs=ptrs)
+    else:
+        native.fuse_planes(plan, tiles, canvas, flats)
+    torch.cuda.synchronize()
+    return canvas.cpu().numpy(), plan
+
+
+def random_rects(rng, n, th, tw, ch, cw):
+    rects = []
+    for _ in range(n):
+        sy, sx = int(rng.integers(0, th // 3)), int(rng.integers(0, tw // 3))
+        rects.append((sy, sx, int(rng.integers(1, th - sy + 1)), int(rng.integers(1, tw - sx + 1)),
+                      int(rng.integers(0, ch)), int(rng.integers(0, cw))))
+    return np.array(rects)
+
+
+@pytest.mark.parametrize('dtype', ['uint16', 'uint8'])
+@pytest.mark.parametrize('seed', range(4))
+def test_overwrite_random_rects(seed, dtype):
+    rng = np.random.default_rng(seed)
+    th, tw = int(rng.integers(30, 90)), int(rng.integers(30, 200))
+    ch, cw = int(rng.integers(50, 400)), int(rng.integers(50, 700))    # odd pitches: every alignment phase
+    n = int(rng.integers(1, 30))
+    rects = random_rects(rng, n, th, tw, ch, cw)
+    tiles = rng.integers(0, np.iinfo(dtype).max + 1, size=(1, n, th, tw)).astype(dtype)
+    got, _ = run_fuse(rects, tiles, ch, cw, use_ptrs=bool(seed % 2))
+    want = O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw)
+    np.testing.assert_array_equal(got[0], want)
+
+
+@pytest.mark.parametrize('fdtype', ['float32', 'float64'])
+@pytest.mark.parametrize('dtype', ['uint16', 'uint8'])
+def test_overwrite_flatfield_multi_plane(dtype, fdtype):
+    rng = np.random.default_rng(11)
+    th, tw, ch, cw, n, planes = 64, 100, 231, 333, 9, 3
+    rects = random_rects(rng, n, th, tw, ch - 20, cw - 20)
+    tiles = rng.integers(0, np.iinfo(dtype).max + 1, size=(planes, n, th, tw)).astype(dtype)
+    flats = []
+    for p in range(planes):
+        f = (0.3 + 1.4 * rng.random((th, tw))).astype(fdtype)
+        f[0, :6] = [0.0, 1e-9, 1.0, 0.5, 3.0, 1.0000001]     # inf / clip / exact paths
+        flats.append(f)
+    flats[1] = None      # a channel without a flatfield: identity (stitcher.py:608,611)
+    tiles[:, :, 0, 0] = 0   # 0/0 -> NaN -> 0
+    got, _ = run_fuse(rects, tiles, ch, cw, flats_np=flats, n_planes=planes)
+    for p in range(planes):
+        want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, flats[p])
+        np.testing.assert_array_equal(got[p], want)
+
+
+def test_flatfield_golden_vectors_through_kernel():
+    import os
+    from helpers import GOLDEN
+    v = np.load(os.path.join(GOLDEN, 'flatfield_vectors.npz'))
+    tile = v['tile']
+    th, tw = tile.shape
+    rects = np.array([(0, 0, th, tw, 0, 0)])
+    for dt in ('float32', 'float64'):
+        got, _ = run_fuse(rects, tile[None, None], th, tw, flats_np=[v[f'ff_{dt}']])
+        np.testing.assert_array_equal(got[0], v[f'out_{dt}'])
+
+
+def test_grid_geometry_like_reference_config2_scaled():
+    """Registered 8x8 grid geometry (crops, skew, oversize canvas) at 1/8 scale."""
+    spec = synth.GridSpec(rows=8, cols=8, tile_h=256, tile_w=256, ov_y=30, ov_x=30, seed=2)
+    h_shift, v_shift = (3, -30), (-30, -2)
+    xs = [spec.stage_mm(0, c)[0] for c in range(8)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(8)]
+    wc, hc, _ = O.output_dimensions(xs, ys, 256, 256, spec.pixel_size_um, True, h_shift, v_shift)
+    rects, tiles = [], []
+    order = sorted(range(64), key=lambda f: str(f))        # sorted-filename order of fov numbers
+    for fov in order:
+        r, c = divmod(fov, 8)
+        info = dict(x=xs[c], y=ys[r])
+        x_px, y_px, top, bottom, left, right = O.tile_rect(info, xs, ys, 256, 256, spec.pixel_size_um, True, h_shift,
+                                                           v_shift, None, 0, wc, hc)
+        rects.append((top, left, 256 - top - bottom, 256 - left - right, y_px + top, x_px + left))
+        tiles.append(spec.tile(r, c))
+    rects = np.array(rects)
+    tiles = np.stack(tiles)[None]
+    got, plan = run_fuse(rects, tiles, hc, wc)
+    want = O.fuse_plane_overwrite(list(tiles[0]), rects, hc, wc)
+    np.testing.assert_array_equal(got[0], want)
+    assert plan.covered_voxels == int((want != 0).sum())
+
+
+@pytest.mark.parametrize('out_dtype', ['float32', 'uint16'])
+@pytest.mark.parametrize('with_flat', [False, True])
+def test_feather_matches_oracle_definition(out_dtype, with_flat):
+    rng = np.random.default_rng(21)
+    th, tw, ch, cw = 48, 64, 150, 190
+    rects = np.array([(0, 0, th, tw, int(y), int(x)) for y, x in
+                      zip(rng.integers(0, ch - 30, 10), rng.integers(0, cw - 30, 10))])
+    tiles = rng.integers(0, 65536, size=(1, 10, th, tw)).astype(np.uint16)
+    flat = (0.6 + 0.8 * rng.random((th, tw))).astype(np.float32) if with_flat else None
+    got, plan = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=[flat] if with_flat else None,
+                         out_dtype=out_dtype)
+    want = O.fuse_plane_feather(list(tiles[0]), rects, ch, cw, flat, out_dtype=np.dtype(out_dtype).type)
+    assert plan.max_refs >= 2
+    if out_dtype == 'float32':
+        np.testing.assert_allclose(got[0], want, rtol=1e-5, atol=0)   # north_star: 1e-5 relative
+    else:
+        assert np.abs(got[0].astype(np.int64) - want.astype(np.int64)).max() <= 1
+        assert (got[0] != want).mean() < 1e-3     # only .5 ties may differ
+
+
+def test_synth_device_generator_equals_numpy():
+    torch = _torch()
+    for dtype in ('uint16', 'uint8'):
+        spec = synth.GridSpec(rows=2, cols=3, tile_h=40, tile_w=72, ov_y=10, ov_x=12, seed=31, dtype=dtype,
+                              jy=-3, jx=2, base=5)   # base 5 with negative drift: negative scene coordinates
+        desc = np.zeros(6, dtype=native.SYNTH_DTYPE)
+        for r in range(2):
+            for c in range(3):
+                i = r * 3 + c
+                oy, ox = spec.origin(r, c)
+                desc[i] = (spec.scene_seed(0, 0, 1, 2) & (2 ** 64 - 1),
+                           spec.noise_seed(0, 0, 1, 2, spec.fov_index(r, c)) & (2 ** 64 - 1), oy - 20, ox - 20)
+        got = native.synth_tiles(desc, 40, 72, spec.noise, dtype, torch.device('cuda:0')).cpu().numpy()
+        for r in range(2):
+            for c in range(3):
+                oy, ox = spec.origin(r, c)
+                v = synth.scene_patch(spec.scene_seed(0, 0, 1, 2), oy - 20, ox - 20, 40, 72) + \
+                    synth.noise_patch(spec.noise_seed(0, 0, 1, 2, spec.fov_index(r, c)), 40, 72, spec.noise)
+                want = (v >> 8).astype(np.uint8) if dtype == 'uint8' else v.astype(np.uint16)
+                np.testing.assert_array_equal(got[r * 3 + c], want)
+
+
+def test_fuse_argument_errors_are_reported():
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    plan = native.FusePlan(np.array([(0, 0, 8, 8, 0, 0)]), 8, 8, 16, 16)
+    tiles = torch.zeros((1, 1, 8, 8), dtype=torch.uint16, device=dev)
+    with pytest.raises(native.NativeError, match='overwrite mode keeps the tile dtype'):
+        native.fuse_planes(plan, tiles, torch.zeros((1, 16, 16), dtype=torch.float32, device=dev))
+    with pytest.raises(native.NativeError, match='geometry differs'):
+        native.fuse_planes(plan, tiles, torch.zeros((1, 16, 24), dtype=torch.uint16, device=dev))
+    with pytest.raises(ValueError, match='elements'):
+        native.fuse_planes(plan, tiles[:, :, :4], torch.zeros((1, 16, 16), dtype=torch.uint16, device=dev))

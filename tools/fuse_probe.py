@@ -1,0 +1,66 @@
+"""Quick device probe: fusion throughput on a registered grid (not the bench contract)."""
+import argparse
+import sys
+import os
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_stitcher_amd import native, placement, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--grid', type=int, default=16)
+    ap.add_argument('--planes', type=int, default=8)
+    ap.add_argument('--tile', type=int, default=2048)
+    ap.add_argument('--ov', type=int, default=244)
+    ap.add_argument('--flat', choices=['none', 'f32', 'f64'], default='none')
+    ap.add_argument('--steps', type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    g, T = a.grid, a.tile
+    shifts = placement.Shifts((3, -a.ov), (-a.ov, -2))
+    rects = placement.grid_rects(g, g, T, T, shifts)
+    wc, hc = placement.canvas_size(g, g, T, T, use_registration=True, shifts=shifts)
+    t0 = time.time()
+    plan = native.FusePlan(rects, T, T, hc, wc)
+    print(f'plan: {plan.n_spans} spans, {plan.n_items} items, table {plan.table.nbytes/1e6:.2f} MB, '
+          f'{time.time()-t0:.3f}s; canvas {hc}x{wc}; covered {plan.covered_voxels/(hc*wc):.3f}')
+    spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=a.ov, ov_x=a.ov, seed=1)
+    tiles = torch.empty((a.planes, g * g, T, T), dtype=torch.uint16, device=dev)
+    for p in range(a.planes):
+        desc = np.zeros(g * g, dtype=native.SYNTH_DTYPE)
+        for r in range(g):
+            for c in range(g):
+                oy, ox = spec.origin(r, c)
+                desc[r * g + c] = (spec.scene_seed(0, 0, p, 0) % 2**64, spec.noise_seed(0, 0, p, 0, r * g + c) % 2**64, oy, ox)
+        native.synth_tiles(desc, T, T, 200, 'uint16', dev, out=tiles[p])
+    torch.cuda.synchronize()
+    canvas = torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)
+    flats = None
+    if a.flat != 'none':
+        ff = torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)).to(dev)
+        flats = [ff] * a.planes
+    for _ in range(2):
+        native.fuse_planes(plan, tiles, canvas, flats)
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(a.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        native.fuse_planes(plan, tiles, canvas, flats)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
+    vox = a.planes * hc * wc
+    alg = a.planes * (plan.covered_voxels * 4 + (hc * wc - plan.covered_voxels) * 2)
+    print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
+          f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
+
+
+if __name__ == '__main__':
+    main()
