@@ -1,11 +1,717 @@
+// Registration kernels for gfx950: batched phase cross-correlation of tile-overlap crops.
+//
+// Replaces, per pair of tiles: normalize_image (stitcher.py:613-617), the crops of
+// calculate_horizontal_shift / calculate_vertical_shift (:504-506, :517-519) and
+// skimage.registration.phase_cross_correlation(upsample_factor=u)
+// (skimage/registration/_phase_cross_correlation.py:189-276 of 0.18.3, plus the one-line
+// `normalization="phase"` of >= 0.19).  All arithmetic is float64/complex128 like the reference
+// (uint16 input -> complex128 FFT).  No dense contraction worth MFMA: the work is FFT butterflies
+// in LDS and two small upsampled-DFT sums.
+//
+// Pipeline (one launch each, batched over pairs; spectra live in the caller's workspace and stay
+// L2 / Infinity-Cache resident -- 2 x n0 x (n1/2+1) complex128 per pair):
+//   K0 init        twiddle tables exp(-2 pi i k/n) for both axes and exp(+2 pi i j/(n u)) for the
+//                  upsampled DFT (sincospi on exactly reduced integer arguments)
+//   K1 rows fwd    crop + min-max normalise + two-for-one real FFT along axis 1:
+//                  z = ref_row + i mov_row, one complex FFT, split into the two half spectra
+//   K2 columns     FFT along axis 0 of both half spectra (tiles of TC columns through LDS),
+//                  cross-power product F conj(G) [/ max(|.|, 100 eps)], |F|^2 / |G|^2 partial sums,
+//                  product stored for K4, inverse FFT along axis 0 in place
+//   K3 rows inv    Hermitian-extend two rows, one inverse complex FFT -> two real correlation rows,
+//                  |.| and per-block argmax (first index wins ties, NaN wins like numpy)
+//   K4a peak       reduce block partials -> whole-pixel peak, wrap to signed shift (skimage :215-220)
+//   K4b upsample 1 D1[k0][b] = sum_k1 P[k0][k1] e^{+2 pi i (b-off1) f1[k1]}   (skimage :63-75, last axis)
+//   K4c upsample 2 cc_up[a][b] = sum_k0 D1[k0][b] e^{+2 pi i (a-off0) f0[k0]}, argmax |.| (skimage :244)
 #include <hip/hip_runtime.h>
+
 #include "common.h"
+
 using namespace sq;
-extern "C" int sq_tile_minmax(const void *const *, const void *, int64_t, int32_t, int32_t, int32_t, int32_t, int32_t,
-                              uint32_t *, void *) {
-    return fail(SQ_ERR_UNSUPPORTED, "sq_tile_minmax: not built yet");
+
+namespace {
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
+
+constexpr int MAX_POW2 = 4096;     // longest power-of-two line handled in LDS
+constexpr int MAX_DIRECT = 2048;   // longest non-power-of-two line (direct DFT, O(n^2))
+
+inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
+
+// Workspace carve-up, identical on host (sizes) and device (pointers).
+struct Layout {
+    int64_t tw0, tw1, up0, up1, spectra, amps, rowmax, d1, peak, total;
+    int n0, n1, n1h, region, up;
+    int64_t per_pair_spec;
+};
+
+Layout make_layout(int n_pairs, int n0, int n1, int up) {
+    Layout L{};
+    L.n0 = n0;
+    L.n1 = n1;
+    L.n1h = n1 / 2 + 1;
+    L.up = up;
+    L.region = (int)((up * 3 + 1) / 2);   // ceil(up * 1.5) for integer up (skimage :233)
+    int64_t off = 0;
+    L.tw0 = off;
+    off += align16((int64_t)n0 * 16);
+    L.tw1 = off;
+    off += align16((int64_t)n1 * 16);
+    L.up0 = off;
+    off += align16((int64_t)n0 * up * 16);
+    L.up1 = off;
+    off += align16((int64_t)n1 * up * 16);
+    L.per_pair_spec = (int64_t)n0 * L.n1h * 16;
+    L.spectra = off;
+    off += 2 * L.per_pair_spec * n_pairs;
+    L.amps = off;
+    off += align16((int64_t)n_pairs * L.n1h * 16);            // (|F|^2, |G|^2) per column
+    L.rowmax = off;
+    off += align16((int64_t)n_pairs * ((n0 + 1) / 2) * 16);   // (|cc| value, flat index) per row pair
+    L.d1 = off;
+    off += align16((int64_t)n_pairs * n0 * L.region * 16);
+    L.peak = off;
+    off += align16((int64_t)n_pairs * 16);                    // 4 ints per pair
+    L.total = off;
+    return L;
 }
-extern "C" int64_t sq_register_workspace_bytes(int32_t, int32_t, int32_t, int32_t) { return 0; }
-extern "C" int sq_register_pairs(const sq_register_args *, void *) {
-    return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: not built yet");
+
+struct RegParams {
+    const void *const *tile_ptrs;
+    const void *tile_base;
+    int64_t tile_stride;
+    int32_t tile_pitch;
+    const uint32_t *minmax;
+    const sq_pair *pairs;
+    sq_pair_result *results;
+    char *ws;
+    Layout L;
+    int32_t n_pairs, normalization, tc;
+};
+
+// ---------------------------------------------------------------------------------------------
+// line FFT in LDS
+// ---------------------------------------------------------------------------------------------
+// Power of two: in-place radix-2 decimation in time; tw[k] = exp(-2 pi i k / n), k < n/2.
+// Otherwise: direct DFT with tw[j] = exp(-2 pi i j / n), j < n, result written back to x via tmp.
+// INV conjugates the twiddles (no 1/n scaling anywhere: only argmax and ratios are used).
+template <bool INV>
+__device__ void line_fft(cplx *x, cplx *tmp, int n, const cplx *__restrict__ tw, int tid, int nt) {
+    if ((n & (n - 1)) == 0) {
+        const int logn = 31 - __clz(n);
+        for (int i = tid; i < n; i += nt) {
+            const int j = (int)(__brev((unsigned)i) >> (32 - logn));
+            if (i < j) {
+                const cplx a = x[i];
+                x[i] = x[j];
+                x[j] = a;
+            }
+        }
+        __syncthreads();
+        for (int s = 1; s <= logn; ++s) {
+            const int half = 1 << (s - 1);
+            const int tstride = n >> s;
+            for (int b = tid; b < n / 2; b += nt) {
+                const int k = b & (half - 1);
+                const int i = ((b >> (s - 1)) << s) + k;
+                cplx w = tw[k * tstride];
+                if (INV) w.im = -w.im;
+                const cplx t = cmul(w, x[i + half]);
+                const cplx u = x[i];
+                x[i] = cadd(u, t);
+                x[i + half] = csub(u, t);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int k = tid; k < n; k += nt) {
+            cplx acc = {0.0, 0.0};
+            int idx = 0;
+            for (int j = 0; j < n; ++j) {
+                cplx w = tw[idx];
+                if (INV) w.im = -w.im;
+                acc = cadd(acc, cmul(x[j], w));
+                idx += k;
+                if (idx >= n) idx -= n;
+            }
+            tmp[k] = acc;
+        }
+        __syncthreads();
+        for (int k = tid; k < n; k += nt) x[k] = tmp[k];
+        __syncthreads();
+    }
+}
+
+// several independent lines in one block: the block's threads are split into groups of `tpl`
+// threads, one group per line; all groups execute the same barriers.
+template <bool INV>
+__device__ void lines_fft(cplx *base, cplx *tmpbase, int n, int nlines, const cplx *tw, int tid, int nt) {
+    // every thread walks all lines (barriers must be uniform); threads stride inside a line
+    for (int l = 0; l < nlines; ++l) line_fft<INV>(base + (int64_t)l * n, tmpbase, n, tw, tid, nt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: tables
+// ---------------------------------------------------------------------------------------------
+__global__ void init_tables_kernel(RegParams P) {
+    const Layout &L = P.L;
+    cplx *tw0 = reinterpret_cast<cplx *>(P.ws + L.tw0);
+    cplx *tw1 = reinterpret_cast<cplx *>(P.ws + L.tw1);
+    cplx *up0 = reinterpret_cast<cplx *>(P.ws + L.up0);
+    cplx *up1 = reinterpret_cast<cplx *>(P.ws + L.up1);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = gid; k < L.n0; k += stride) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)L.n0, &s, &c);
+        tw0[k] = {c, s};
+    }
+    for (int64_t k = gid; k < L.n1; k += stride) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)L.n1, &s, &c);
+        tw1[k] = {c, s};
+    }
+    const int64_t m0 = (int64_t)L.n0 * L.up, m1 = (int64_t)L.n1 * L.up;
+    for (int64_t j = gid; j < m0; j += stride) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)m0, &s, &c);
+        up0[j] = {c, s};
+    }
+    for (int64_t j = gid; j < m1; j += stride) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)m1, &s, &c);
+        up1[j] = {c, s};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-tile min / max (normalize_image's two reductions)
+// ---------------------------------------------------------------------------------------------
+__global__ void minmax_init_kernel(uint32_t *mm, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        mm[2 * i] = 0xFFFFFFFFu;
+        mm[2 * i + 1] = 0u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_kernel(const void *const *tile_ptrs, const void *tile_base,
+                                                     int64_t tile_stride, int tile_h, int tile_w, int pitch,
+                                                     uint32_t *mm) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int VEC = 16 / sizeof(T);
+    const int t = blockIdx.y;
+    const T *tile = tile_ptrs ? static_cast<const T *>(tile_ptrs[t]) : static_cast<const T *>(tile_base) + t * tile_stride;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int y = wave; y < tile_h; y += nwaves) {
+        const T *row = tile + (int64_t)y * pitch;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(row) / sizeof(T)) & (VEC - 1));
+        const int head = mis ? min(tile_w, VEC - mis) : 0;
+        const int nvec = (tile_w - head) / VEC;
+        for (int v = lane; v < nvec; v += 64) {
+            const u32x4 px = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(
+                (const __attribute__((address_space(1))) char *)(row + head + v * VEC));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (sizeof(T) == 2) {
+                    const uint32_t a = px[q] & 0xFFFFu, b = px[q] >> 16;
+                    lo = min(lo, min(a, b));
+                    hi = max(hi, max(a, b));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t a = (px[q] >> (8 * e)) & 0xFFu;
+                        lo = min(lo, a);
+                        hi = max(hi, a);
+                    }
+                }
+            }
+        }
+        for (int x = lane; x < head; x += 64) {
+            const uint32_t a = row[x];
+            lo = min(lo, a);
+            hi = max(hi, a);
+        }
+        for (int x = head + nvec * VEC + lane; x < tile_w; x += 64) {
+            const uint32_t a = row[x];
+            lo = min(lo, a);
+            hi = max(hi, a);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if (lane == 0) {
+        atomicMin(&mm[2 * t], lo);
+        atomicMax(&mm[2 * t + 1], hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: crop + normalise + two-for-one FFT along axis 1
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ double normalised(const T *tile, int64_t idx, double lo, double range) {
+    // ((img - min) / (max - min) * dtype_max).astype(dtype)   (stitcher.py:615-617)
+    // range < 0 (a min > max entry in the table) means "already normalised": use the pixel as is
+    if (range < 0.0) return (double)((uint32_t)tile[idx]);
+    const double scale = sizeof(T) == 1 ? 255.0 : 65535.0;
+    const double v = (double)((uint32_t)tile[idx]) - lo;   // exact: uint - uint, never negative
+    const double q = (v / range) * scale;                  // 0/0 -> NaN -> 0 below, as the x86 cast does
+    return q == q ? (double)(T)q : 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout &L = P.L;
+    const int n1 = L.n1, n1h = L.n1h;
+    cplx *x = reinterpret_cast<cplx *>(smem);
+    cplx *tmp = x + n1;
+    const int pair = blockIdx.y, r = blockIdx.x;
+    const sq_pair pr = P.pairs[pair];
+    const T *ref = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.ref_tile])
+                               : static_cast<const T *>(P.tile_base) + pr.ref_tile * P.tile_stride;
+    const T *mov = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.mov_tile])
+                               : static_cast<const T *>(P.tile_base) + pr.mov_tile * P.tile_stride;
+    const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
+    const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t rbase = (int64_t)(pr.ref_y0 + r) * P.tile_pitch + pr.ref_x0;
+    const int64_t mbase = (int64_t)(pr.mov_y0 + r) * P.tile_pitch + pr.mov_x0;
+    for (int j = tid; j < n1; j += nt) x[j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+    __syncthreads();
+    line_fft<false>(x, tmp, n1, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r * n1h;
+    cplx *B = A + (int64_t)L.n0 * n1h;
+    for (int k = tid; k < n1h; k += nt) {
+        const cplx zk = x[k], zc = cconj(x[k ? n1 - k : 0]);
+        // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
+        A[k] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
+        const cplx d = {zk.re - zc.re, zk.im - zc.im};
+        B[k] = {0.5 * d.im, -0.5 * d.re};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: columns -- FFT both spectra along axis 0, cross-power product, inverse along axis 0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void columns_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout &L = P.L;
+    const int n0 = L.n0, n1h = L.n1h, tc = P.tc;
+    cplx *f = reinterpret_cast<cplx *>(smem);   // [tc][n0]
+    cplx *g = f + (int64_t)tc * n0;             // [tc][n0]
+    cplx *tmp = g + (int64_t)tc * n0;           // [n0] (direct DFT only)
+    __shared__ double red[2][4];
+    const int pair = blockIdx.y, c0 = blockIdx.x * tc;
+    const int ncol = min(tc, n1h - c0);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
+    cplx *B = A + (int64_t)n0 * n1h;
+    for (int i = tid; i < n0 * ncol; i += nt) {
+        const int r = i / ncol, c = i - r * ncol;
+        f[(int64_t)c * n0 + r] = A[(int64_t)r * n1h + c0 + c];
+        g[(int64_t)c * n0 + r] = B[(int64_t)r * n1h + c0 + c];
+    }
+    __syncthreads();
+    const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
+    lines_fft<false>(f, tmp, n0, ncol, tw0, tid, nt);
+    lines_fft<false>(g, tmp, n0, ncol, tw0, tid, nt);
+    const double eps100 = 100.0 * 2.220446049250313e-16;
+    double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
+    for (int c = 0; c < ncol; ++c) {
+        double sf = 0.0, sg = 0.0;
+        for (int r = tid; r < n0; r += nt) {
+            const cplx F = f[(int64_t)c * n0 + r], G = g[(int64_t)c * n0 + r];
+            sf += F.re * F.re + F.im * F.im;
+            sg += G.re * G.re + G.im * G.im;
+            cplx pr = cmul(F, cconj(G));                              // skimage :211
+            if (P.normalization == SQ_NORM_PHASE) {
+                // image_product /= max(|.|, 100 eps); numpy divides complex by real as x * (1/c)
+                const double scl = 1.0 / fmax(hypot(pr.re, pr.im), eps100);
+                pr.re *= scl;
+                pr.im *= scl;
+            }
+            f[(int64_t)c * n0 + r] = pr;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sf += __shfl_xor(sf, off);
+            sg += __shfl_xor(sg, off);
+        }
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = sf;
+            red[1][tid >> 6] = sg;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < (nt >> 6); ++w) {
+                a += red[0][w];
+                b += red[1][w];
+            }
+            amps[2 * c] = a;
+            amps[2 * c + 1] = b;
+        }
+        __syncthreads();
+    }
+    // the product is what the upsampled DFT reads (skimage :239): keep it in B
+    for (int i = tid; i < n0 * ncol; i += nt) {
+        const int r = i / ncol, c = i - r * ncol;
+        B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
+    }
+    __syncthreads();
+    lines_fft<true>(f, tmp, n0, ncol, tw0, tid, nt);
+    for (int i = tid; i < n0 * ncol; i += nt) {
+        const int r = i / ncol, c = i - r * ncol;
+        A[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: inverse along axis 1 (two real rows per complex FFT) + |.| + block argmax
+// ---------------------------------------------------------------------------------------------
+struct Best {
+    double v;
+    long long idx;
+    int nan;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // numpy argmax: NaN is the maximum; first occurrence wins
+    if (a.nan != b.nan) return a.nan ? a : b;
+    if (a.nan) return a.idx < b.idx ? a : b;
+    if (a.v != b.v) return a.v > b.v ? a : b;
+    return a.idx < b.idx ? a : b;
+}
+__device__ __forceinline__ Best make_best(double v, long long idx) { return {v, idx, v != v ? 1 : 0}; }
+__device__ Best block_best(Best b, int tid, int nt) {
+    __shared__ double sv[4];
+    __shared__ long long si[4];
+    __shared__ int sn[4];
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(b.v, off);
+        o.idx = __shfl_xor(b.idx, off);
+        o.nan = __shfl_xor(b.nan, off);
+        b = better(b, o);
+    }
+    if ((tid & 63) == 0) {
+        sv[tid >> 6] = b.v;
+        si[tid >> 6] = b.idx;
+        sn[tid >> 6] = b.nan;
+    }
+    __syncthreads();
+    Best r = {sv[0], si[0], sn[0]};
+    for (int w = 1; w < (nt >> 6); ++w) r = better(r, Best{sv[w], si[w], sn[w]});
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout &L = P.L;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h;
+    cplx *x = reinterpret_cast<cplx *>(smem);
+    cplx *tmp = x + n1;
+    const int pair = blockIdx.y, rp = blockIdx.x;
+    const int y0 = 2 * rp, y1 = min(2 * rp + 1, n0 - 1);   // odd n0: the last block repeats its row
+    const bool two = (2 * rp + 1) < n0;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const cplx *Q = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
+    const cplx *q0 = Q + (int64_t)y0 * n1h, *q1 = Q + (int64_t)y1 * n1h;
+    for (int k = tid; k < n1; k += nt) {
+        // Hermitian extension of the half spectrum of a real row: X[n1-k] = conj X[k]
+        cplx a, b;
+        if (k < n1h) {
+            a = q0[k];
+            b = q1[k];
+        } else {
+            a = cconj(q0[n1 - k]);
+            b = cconj(q1[n1 - k]);
+        }
+        if (!two) b = {0.0, 0.0};
+        x[k] = {a.re - b.im, a.im + b.re};   // a + i b
+    }
+    __syncthreads();
+    line_fft<true>(x, tmp, n1, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    Best best = {-1.0, (long long)1 << 62, 0};
+    for (int k = tid; k < n1; k += nt) {
+        best = better(best, make_best(fabs(x[k].re), (long long)y0 * n1 + k));
+        if (two) best = better(best, make_best(fabs(x[k].im), (long long)y1 * n1 + k));
+    }
+    best = block_best(best, tid, nt);
+    if (tid == 0) {
+        double *out = reinterpret_cast<double *>(P.ws + L.rowmax) + ((int64_t)pair * ((n0 + 1) / 2) + rp) * 2;
+        out[0] = best.v;   // NaN stays NaN
+        reinterpret_cast<long long *>(out)[1] = best.idx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4a: whole-pixel peak
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
+    const Layout &L = P.L;
+    const int pair = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nrp = (L.n0 + 1) / 2;
+    const double *rm = reinterpret_cast<const double *>(P.ws + L.rowmax) + (int64_t)pair * nrp * 2;
+    Best best = {-1.0, (long long)1 << 62, 0};
+    for (int i = tid; i < nrp; i += nt) best = better(best, make_best(rm[2 * i], reinterpret_cast<const long long *>(rm)[2 * i + 1]));
+    best = block_best(best, tid, nt);
+    if (tid == 0) {
+        const int py = (int)(best.idx / L.n1), px = (int)(best.idx % L.n1);
+        // shifts[shifts > fix(n/2)] -= n   (skimage :217-220)
+        const int sy = py > L.n0 / 2 ? py - L.n0 : py;
+        const int sx = px > L.n1 / 2 ? px - L.n1 : px;
+        int *pk = reinterpret_cast<int *>(P.ws + L.peak) + 4 * pair;
+        pk[0] = sy;
+        pk[1] = sx;
+        sq_pair_result &res = P.results[pair];
+        res.coarse[0] = sy;
+        res.coarse[1] = sx;
+        res.fine[0] = res.fine[1] = 0;
+        // |cc| at the whole-pixel peak, with ifftn's 1/(n0 n1); sign is not recoverable from |.|,
+        // the upsampled stage overwrites this with the complex value when u > 1
+        res.ccmax_re = best.v / ((double)L.n0 * (double)L.n1);
+        res.ccmax_im = 0.0;
+        const double *amps = reinterpret_cast<const double *>(P.ws + L.amps) + (int64_t)pair * L.n1h * 2;
+        double sa = 0.0, sb = 0.0;
+        for (int k = 0; k < L.n1h; ++k) {
+            // a column and its Hermitian mirror carry the same energy
+            const double wgt = (k == 0 || (2 * k == L.n1)) ? 1.0 : 2.0;
+            sa += wgt * amps[2 * k];
+            sb += wgt * amps[2 * k + 1];
+        }
+        if (L.up == 1) {   // skimage :224-228 divides by size in this branch only
+            sa /= (double)L.n0 * (double)L.n1;
+            sb /= (double)L.n0 * (double)L.n1;
+        }
+        res.src_amp = sa;
+        res.tgt_amp = sb;
+    }
+}
+
+// numpy.fft.fftfreq(n, d=u)[k] * (n*u): the signed integer frequency
+__device__ __forceinline__ int signed_freq(int k, int n) { return k < (n - 1) / 2 + 1 ? k : k - n; }
+__device__ __forceinline__ int posmod(long long a, int m) {
+    int r = (int)(a % m);
+    return r < 0 ? r + m : r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b: D1[k0][b] = sum_{k1 < n1} P[k0][k1] * exp(+2 pi i (b - off1) f1[k1])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
+    const Layout &L = P.L;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, R = L.region, up = L.up;
+    const int pair = blockIdx.y, k0 = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
+    // shifts = round(shifts*u)/u is the integer peak; offset = fix(R/2) - shift*u (skimage :232-238)
+    const int off1 = R / 2 - pk[1] * up;
+    const cplx *Pm = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)n0 * n1h;
+    const cplx *row = Pm + (int64_t)k0 * n1h;
+    const cplx *mir = Pm + (int64_t)((n0 - k0) % n0) * n1h;   // P[k0][n1-k] = conj P[-k0][k]
+    const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up1);
+    const int M = n1 * up;
+    __shared__ cplx part[4];
+    cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + k0) * R;
+    for (int b = 0; b < R; ++b) {
+        cplx acc = {0.0, 0.0};
+        const long long mb = b - off1;
+        for (int k1 = tid; k1 < n1; k1 += nt) {
+            const cplx v = k1 < n1h ? row[k1] : cconj(mir[n1 - k1]);
+            const cplx e = E[posmod(mb * signed_freq(k1, n1), M)];
+            acc = cadd(acc, cmul(v, e));
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            acc.re += __shfl_xor(acc.re, o);
+            acc.im += __shfl_xor(acc.im, o);
+        }
+        if ((tid & 63) == 0) part[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            cplx s = part[0];
+            for (int w = 1; w < (nt >> 6); ++w) s = cadd(s, part[w]);
+            D1[b] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4c: cc_up[a][b] = sum_{k0} D1[k0][b] * exp(+2 pi i (a - off0) f0[k0]); argmax |.| row-major
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_peak_kernel(RegParams P) {
+    const Layout &L = P.L;
+    const int n0 = L.n0, R = L.region, up = L.up;
+    const int pair = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
+    const int off0 = R / 2 - pk[0] * up;
+    const cplx *D1 = reinterpret_cast<const cplx *>(P.ws + L.d1) + (int64_t)pair * n0 * R;
+    const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up0);
+    const int M = n0 * up;
+    Best best = {-1.0, (long long)1 << 62, 0};
+    double bre = 0.0, bim = 0.0;
+    for (int o = tid; o < R * R; o += nt) {
+        const int a = o / R, b = o - a * R;
+        const long long ma = a - off0;
+        cplx acc = {0.0, 0.0};
+        for (int k0 = 0; k0 < n0; ++k0) {
+            const cplx e = E[posmod(ma * signed_freq(k0, n0), M)];
+            acc = cadd(acc, cmul(D1[(int64_t)k0 * R + b], e));
+        }
+        const Best cand = make_best(hypot(acc.re, acc.im), o);
+        const Best nb = better(best, cand);
+        if (nb.idx == o) {
+            bre = acc.re;
+            bim = acc.im;
+        }
+        best = nb;
+    }
+    // block argmax; the winner's complex value travels with it
+    __shared__ double sre[256], sim[256], sv[256];
+    __shared__ long long si[256];
+    __shared__ int sn[256];
+    sre[tid] = bre;
+    sim[tid] = bim;
+    sv[tid] = best.v;
+    si[tid] = best.idx;
+    sn[tid] = best.nan;
+    __syncthreads();
+    if (tid == 0) {
+        int w = 0;
+        Best r = {sv[0], si[0], sn[0]};
+        for (int t = 1; t < nt; ++t) {
+            const Best c = {sv[t], si[t], sn[t]};
+            const Best nb = better(r, c);
+            if (nb.idx != r.idx) w = t;
+            r = nb;
+        }
+        sq_pair_result &res = P.results[pair];
+        res.fine[0] = (int)(r.idx / R);
+        res.fine[1] = (int)(r.idx % R);
+        res.ccmax_re = sre[w];
+        res.ccmax_im = sim[w];
+    }
+}
+
+int check_line(int n, const char *axis) {
+    if (n < 2) return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %s length %d < 2", axis, n);
+    if (is_pow2(n) ? n > MAX_POW2 : n > MAX_DIRECT)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported (power of two <= %d, other <= %d)",
+                    axis, n, MAX_POW2, MAX_DIRECT);
+    return SQ_OK;
+}
+
+int pick_threads(int n) { return n <= 128 ? 64 : (n <= 512 ? 128 : 256); }
+
+}  // namespace
+
+extern "C" int sq_tile_minmax(const void *const *tile_ptrs_dev, const void *tile_base_dev, int64_t tile_stride,
+                              int32_t n_tiles, int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype,
+                              uint32_t *out_minmax_dev, void *stream_) {
+    if ((!tile_ptrs_dev && !tile_base_dev) || !out_minmax_dev || n_tiles < 0 || tile_h <= 0 || tile_w <= 0 ||
+        tile_pitch < tile_w)
+        return fail(SQ_ERR_INVALID, "sq_tile_minmax: bad arguments (n_tiles=%d %dx%d pitch %d)", n_tiles, tile_h, tile_w,
+                    tile_pitch);
+    if (tile_dtype != SQ_U8 && tile_dtype != SQ_U16) return fail(SQ_ERR_UNSUPPORTED, "sq_tile_minmax: dtype %d", tile_dtype);
+    if (n_tiles == 0) return SQ_OK;
+    if (n_tiles > 65535) return fail(SQ_ERR_UNSUPPORTED, "sq_tile_minmax: more than 65535 tiles per call");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, out_minmax_dev, n_tiles);
+    const int bx = std::max(1, std::min(64, tile_h / 4));
+    dim3 grid(bx, n_tiles);
+    if (tile_dtype == SQ_U16)
+        hipLaunchKernelGGL(minmax_kernel<uint16_t>, grid, dim3(256), 0, s, tile_ptrs_dev, tile_base_dev, tile_stride, tile_h,
+                           tile_w, tile_pitch, out_minmax_dev);
+    else
+        hipLaunchKernelGGL(minmax_kernel<uint8_t>, grid, dim3(256), 0, s, tile_ptrs_dev, tile_base_dev, tile_stride, tile_h,
+                           tile_w, tile_pitch, out_minmax_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_tile_minmax: launch failed: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+extern "C" int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor) {
+    if (n_pairs < 0 || n0 < 2 || n1 < 2 || upsample_factor < 1 || upsample_factor > 100)
+        return fail(SQ_ERR_INVALID, "sq_register_workspace_bytes: bad sizes (pairs=%d crop=%dx%d u=%d)", n_pairs, n0, n1,
+                    upsample_factor);
+    return make_layout(n_pairs, n0, n1, upsample_factor).total;
+}
+
+extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
+    if (!a || (!a->tile_ptrs_dev && !a->tile_base_dev) || !a->minmax_dev || !a->pairs_dev || !a->results_dev ||
+        !a->workspace_dev)
+        return fail(SQ_ERR_INVALID, "sq_register_pairs: NULL argument");
+    if (a->n_pairs < 0 || a->n_pairs > 65535) return fail(SQ_ERR_INVALID, "sq_register_pairs: n_pairs %d out of range", a->n_pairs);
+    if (a->upsample_factor < 1 || a->upsample_factor > 100)
+        return fail(SQ_ERR_INVALID, "sq_register_pairs: upsample_factor %d out of range", a->upsample_factor);
+    if (a->normalization != SQ_NORM_NONE && a->normalization != SQ_NORM_PHASE)
+        return fail(SQ_ERR_INVALID, "normalization must be either phase or None (got %d)", a->normalization);
+    if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: dtype %d", a->tile_dtype);
+    if (a->n0 > a->tile_h || a->n1 > a->tile_w || a->tile_pitch < a->tile_w)
+        return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %dx%d larger than the %dx%d tile", a->n0, a->n1, a->tile_h, a->tile_w);
+    int rc;
+    if ((rc = check_line(a->n0, "axis-0")) != SQ_OK) return rc;
+    if ((rc = check_line(a->n1, "axis-1")) != SQ_OK) return rc;
+    if (a->n0 > 65535) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: n0 too large");
+    const Layout L = make_layout(a->n_pairs, a->n0, a->n1, a->upsample_factor);
+    if (a->workspace_bytes < L.total)
+        return fail(SQ_ERR_WORKSPACE, "sq_register_pairs: workspace %lld < %lld bytes", (long long)a->workspace_bytes, (long long)L.total);
+    if (reinterpret_cast<uintptr_t>(a->workspace_dev) % 16) return fail(SQ_ERR_INVALID, "sq_register_pairs: workspace not 16-byte aligned");
+    if (a->n_pairs == 0) return SQ_OK;
+
+    RegParams P{};
+    P.tile_ptrs = a->tile_ptrs_dev;
+    P.tile_base = a->tile_base_dev;
+    P.tile_stride = a->tile_stride;
+    P.tile_pitch = a->tile_pitch;
+    P.minmax = a->minmax_dev;
+    P.pairs = a->pairs_dev;
+    P.results = a->results_dev;
+    P.ws = static_cast<char *>(a->workspace_dev);
+    P.L = L;
+    P.n_pairs = a->n_pairs;
+    P.normalization = a->normalization;
+    // columns per block: two [tc][n0] complex arrays (+ one scratch line for the direct DFT) in 144 KiB of LDS
+    const int64_t scratch = is_pow2(L.n0) ? 0 : (int64_t)L.n0 * 16;
+    int tc = (int)std::min<int64_t>(8, (144 * 1024 - scratch) / (2 * (int64_t)L.n0 * 16));
+    if (tc < 1) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: axis-0 length %d does not fit LDS", L.n0);
+    P.tc = tc;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+
+    hipLaunchKernelGGL(init_tables_kernel, dim3(64), dim3(256), 0, s, P);
+    const size_t lds_row = (size_t)2 * L.n1 * 16;
+    const int nt1 = pick_threads(L.n1);
+    if (a->tile_dtype == SQ_U16)
+        hipLaunchKernelGGL(rows_forward_kernel<uint16_t>, dim3(L.n0, a->n_pairs), dim3(nt1), lds_row, s, P);
+    else
+        hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3(L.n0, a->n_pairs), dim3(nt1), lds_row, s, P);
+    const size_t lds_col = ((size_t)2 * tc + 1) * L.n0 * 16;
+    if (lds_col > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(columns_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
+        if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: cannot raise LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(256), lds_col, s, P);
+    hipLaunchKernelGGL(rows_inverse_kernel, dim3((L.n0 + 1) / 2, a->n_pairs), dim3(nt1), lds_row, s, P);
+    hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
+    if (a->upsample_factor > 1) {
+        hipLaunchKernelGGL(upsample_rows_kernel, dim3(L.n0, a->n_pairs), dim3(pick_threads(L.n1)), 0, s, P);
+        hipLaunchKernelGGL(upsample_peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: launch failed: %s", hipGetErrorString(e));
+    return SQ_OK;
 }

@@ -1,0 +1,157 @@
+"""Host side of registration: builds crop pairs, calls the HIP pipeline through the C-ABI and
+finishes the few scalar steps the reference does in Python/numpy float64.
+
+Replaces skimage.registration.phase_cross_correlation as called from
+calculate_horizontal_shift / calculate_vertical_shift (stitcher.py:500-524) and the pair
+selection of calculate_shifts (stitcher.py:455-496).  ``register_all_pairs`` is the
+north-star extension (every adjacent pair, batched); the reference itself registers only the
+centre pairs.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import native, placement
+from .placement import Shifts
+
+NORMALIZATIONS = {'phase': native.SQ_NORM_PHASE, None: native.SQ_NORM_NONE, 'none': native.SQ_NORM_NONE}
+
+
+def _norm_code(normalization) -> int:
+    if normalization not in NORMALIZATIONS:
+        raise ValueError("normalization must be either phase or None")   # skimage's message
+    return NORMALIZATIONS[normalization]
+
+
+def shifts_from_results(res: np.ndarray, upsample_factor: int):
+    """RESULT_DTYPE rows -> (shifts [n,2] float64, error [n], phasediff [n]) with the float64
+    arithmetic of skimage (_phase_cross_correlation.py:232-250, :91-106, :78-88)."""
+    shifts = res['coarse'].astype(np.float64)
+    if upsample_factor > 1:
+        shifts = np.round(shifts * upsample_factor) / upsample_factor
+        region = np.ceil(upsample_factor * 1.5)
+        dftshift = np.fix(region / 2.0)
+        up = np.float64(upsample_factor)
+        shifts = shifts + (res['fine'].astype(np.float64) - dftshift) / up
+    ccmax = res['ccmax_re'] + 1j * res['ccmax_im']
+    with np.errstate(all='ignore'):
+        err = np.sqrt(np.abs(1.0 - ccmax * ccmax.conj() / (res['src_amp'] * res['tgt_amp'])))
+    phase = np.arctan2(res['ccmax_im'], res['ccmax_re'])
+    return shifts, err, phase
+
+
+def register_pairs(tiles, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
+                   normalization='phase', minmax=None):
+    """Batched phase cross-correlation on a device tile stack [N, H, W].
+    Returns (shifts [n,2], error [n], phasediff [n]) as numpy arrays."""
+    code = _norm_code(normalization)
+    if minmax is None:
+        minmax = native.tile_minmax(tiles)
+    res = native.register_pairs(tiles, minmax, pairs, n0, n1, upsample_factor, code)
+    return shifts_from_results(res, upsample_factor)
+
+
+def phase_cross_correlation(reference_image, moving_image, *, upsample_factor=1, normalization='phase',
+                            device=None):
+    """Drop-in for the call shape the reference uses (two equal-shape 2-D images already
+    cropped): returns (shifts, error, phasediff).  Images go to the device as their own
+    "tiles"; no min-max stretch is applied (identity range), like skimage."""
+    import torch
+    a = np.ascontiguousarray(reference_image)
+    b = np.ascontiguousarray(moving_image)
+    if a.shape != b.shape:
+        raise ValueError("images must be same shape")
+    if a.ndim != 2 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("device phase_cross_correlation takes 2-D uint8/uint16 images")
+    dev = device or torch.device('cuda:0')
+    tiles = torch.from_numpy(np.stack([a, b])).to(dev)
+    # a (min > max) entry tells the kernel to use the pixels as they are
+    minmax = torch.tensor([[1, 0], [1, 0]], dtype=torch.int32, device=dev)
+    pairs = np.zeros(1, dtype=native.PAIR_DTYPE)
+    pairs[0] = (0, 1, 0, 0, 0, 0)
+    s, e, p = register_pairs(tiles, pairs, a.shape[0], a.shape[1], upsample_factor, normalization, minmax)
+    return s[0], float(e[0]), float(p[0])
+
+
+def horizontal_pair(ref_tile: int, mov_tile: int, height: int, width: int, max_overlap: int):
+    n0, n1, (ry, rx), (my, mx) = placement.horizontal_crop_origins(height, width, max_overlap)
+    return (ref_tile, mov_tile, ry, rx, my, mx), n0, n1
+
+
+def vertical_pair(ref_tile: int, mov_tile: int, height: int, width: int, max_overlap: int):
+    n0, n1, (ry, rx), (my, mx) = placement.vertical_crop_origins(height, width, max_overlap)
+    return (ref_tile, mov_tile, ry, rx, my, mx), n0, n1
+
+
+def horizontal_shift_from(shift: np.ndarray, n1: int) -> Tuple[int, int]:
+    """(stitcher.py:511): python round() of numpy float64 -> banker's rounding."""
+    return round(shift[0]), round(shift[1] - n1)
+
+
+def vertical_shift_from(shift: np.ndarray, n0: int) -> Tuple[int, int]:
+    """(stitcher.py:524)"""
+    return round(shift[0] - n0), round(shift[1])
+
+
+def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], ys: Sequence[float],
+                         pixel_size_um: float, pixel_binning: int, normalization='phase',
+                         scan_pattern: str = 'Unidirectional', tile_index=None, minmax=None) -> Shifts:
+    """calculate_shifts (stitcher.py:422-498) on a device stack of one (channel, z) plane.
+
+    ``tile_index(row, col) -> index into tiles`` (default row-major).  Picks the centre tile
+    and its right / bottom neighbours; S-Pattern adds the pair one row below."""
+    height, width = int(tiles.shape[-2]), int(tiles.shape[-1])
+    idx = tile_index or (lambda r, c: r * n_cols + c)
+    mx, my = placement.registration_crop_widths(xs, ys, width, height, pixel_size_um, pixel_binning)
+    ci, ri = (n_cols - 1) // 2, (n_rows - 1) // 2
+    out = Shifts()
+    if minmax is None:
+        minmax = native.tile_minmax(tiles)
+    hp = []
+    if ci + 1 < n_cols:
+        p, n0, n1 = horizontal_pair(idx(ri, ci), idx(ri, ci + 1), height, width, mx)
+        hp.append(p)
+        if scan_pattern == 'S-Pattern' and ri + 1 < n_rows:
+            hp.append(horizontal_pair(idx(ri + 1, ci), idx(ri + 1, ci + 1), height, width, mx)[0])
+        s, _, _ = register_pairs(tiles, np.array(hp, dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+        out.h_shift = horizontal_shift_from(s[0], n1)
+        if len(hp) > 1:
+            out.h_shift_rev = horizontal_shift_from(s[1], n1)
+            out.h_shift_rev_odd = int(ri % 2 == 0)
+    if scan_pattern == 'S-Pattern' and out.h_shift_rev is None:
+        out.h_shift_rev = (0, 0)
+    if ri + 1 < n_rows:
+        p, n0, n1 = vertical_pair(idx(ri, ci), idx(ri + 1, ci), height, width, my)
+        s, _, _ = register_pairs(tiles, np.array([p], dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+        out.v_shift = vertical_shift_from(s[0], n0)
+    return out
+
+
+def all_pairs(n_rows: int, n_cols: int, height: int, width: int, max_x_overlap: int, max_y_overlap: int,
+              tile_index=None):
+    """Every horizontally / vertically adjacent pair of a grid as two PAIR_DTYPE batches:
+    (h_pairs, (n0, n1)), (v_pairs, (n0, n1))."""
+    idx = tile_index or (lambda r, c: r * n_cols + c)
+    hp, vp = [], []
+    hshape = vshape = (0, 0)
+    for r in range(n_rows):
+        for c in range(n_cols - 1):
+            p, n0, n1 = horizontal_pair(idx(r, c), idx(r, c + 1), height, width, max_x_overlap)
+            hp.append(p)
+            hshape = (n0, n1)
+    for r in range(n_rows - 1):
+        for c in range(n_cols):
+            p, n0, n1 = vertical_pair(idx(r, c), idx(r + 1, c), height, width, max_y_overlap)
+            vp.append(p)
+            vshape = (n0, n1)
+    return (np.array(hp, dtype=native.PAIR_DTYPE), hshape), (np.array(vp, dtype=native.PAIR_DTYPE), vshape)
+
+
+def consensus_shift(shifts: np.ndarray, errors: np.ndarray) -> Tuple[float, float]:
+    """Robust per-axis median of a batch of pair shifts (all-pairs extension)."""
+    ok = np.isfinite(errors)
+    s = shifts[ok] if ok.any() else shifts
+    return float(np.median(s[:, 0])), float(np.median(s[:, 1]))

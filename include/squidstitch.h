@@ -152,7 +152,8 @@ typedef struct sq_register_args {
     const void *tile_base_dev;
     int64_t tile_stride;
     int32_t n_tiles, tile_h, tile_w, tile_pitch, tile_dtype;
-    const uint32_t *minmax_dev; /* from sq_tile_minmax (2 per tile)                     */
+    const uint32_t *minmax_dev; /* from sq_tile_minmax (2 per tile); an entry with min > max
+                                   means "do not normalise this tile" (plain skimage call)  */
     const sq_pair *pairs_dev;
     int32_t n_pairs;
     int32_t n0, n1; /* crop size (rows, cols)                                           */
