@@ -1,0 +1,595 @@
+"""``Stitcher``: the reference's class surface (stitcher.py:31) over the MI355X core.
+
+Same constructor, same method names / argument meaning / error behaviour for the methods a
+front-end touches -- ``run``, ``calculate_shifts``, ``calculate_horizontal_shift``,
+``calculate_vertical_shift``, ``normalize_image``, ``apply_flatfield_correction``,
+``calculate_output_dimensions``, ``stitch_region`` -- and the same state attributes
+(``h_shift``, ``v_shift``, ``h_shift_rev``, ``h_shift_rev_odd``, ``flatfields``,
+``acquisition_metadata``, ``x_positions``, ``y_positions``, ...).  What differs is inside:
+
+* registration and fusion run as HIP kernels through the C-ABI (``native``); there is no CPU
+  path -- a missing library or GPU raises;
+* a region is fused in one launch over all its (channel, z) planes from a device-resident
+  tile stack, instead of one dask ``__setitem__`` layer per file;
+* metadata lookups are indexed once (the reference rescans per file).
+
+Qt is not required: signals are plain callback lists with ``emit``/``connect``.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import random
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import native, placement, registration
+from .omezarr import write_ome_zarr
+from .placement import Shifts
+from .stitcher_parameters import StitchingParameters
+from .tiffio import read_image
+
+_IMAGE_EXT = ('.bmp', '.tiff', 'tif', 'jpg', 'jpeg', 'png')   # as the reference spells them (stitcher.py:169)
+
+
+class Signal:
+    """Tiny stand-in for a Qt signal (stitcher.py:33-37)."""
+
+    def __init__(self, *types):
+        self._slots = []
+
+    def connect(self, fn):
+        self._slots.append(fn)
+
+    def emit(self, *args):
+        for fn in list(self._slots):
+            fn(*args)
+
+
+class Stitcher:
+    def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
+                 normalization: Optional[str] = 'phase'):
+        self.update_progress = Signal(int, int)
+        self.getting_flatfields = Signal()
+        self.starting_stitching = Signal()
+        self.starting_saving = Signal(bool)
+        self.finished_saving = Signal(str, object)
+
+        self.params = params
+        params.validate()
+        self.input_folder = params.input_folder
+        self.output_folder = params.stitched_folder
+        self.output_format = params.output_format
+        self.merge_timepoints = getattr(params, 'merge_timepoints', False)
+        self.merge_hcs_regions = getattr(params, 'merge_hcs_regions', False)
+        self.per_timepoint_region_output_template = os.path.join(
+            self.output_folder, "{timepoint}_stitched", "{region}_stitched" + self.output_format)
+        self.apply_flatfield = params.apply_flatfield
+        self.use_registration = params.use_registration
+        if self.use_registration:
+            self.registration_channel = params.registration_channel
+            self.registration_z_level = params.registration_z_level
+            self.dynamic_registration = params.dynamic_registration
+        self.scan_pattern = params.scan_pattern
+        if fusion_mode not in ('overwrite', 'feather'):
+            raise ValueError("fusion_mode must be 'overwrite' or 'feather'")
+        self.fusion_mode = fusion_mode            # 'feather' is an extension the reference lacks
+        self.normalization = normalization        # scikit-image >= 0.19 default is 'phase'
+        self._device = device
+        self._plan_cache: Dict[tuple, native.FusePlan] = {}
+        self.init_stitching_parameters()
+
+    # ------------------------------------------------------------------ state
+    def init_stitching_parameters(self):
+        """(stitcher.py:98-119)"""
+        self.pixel_size_um = None
+        self.pixel_binning = 1
+        self.acquisition_params = None
+        self.timepoints = []
+        self.regions = []
+        self.channel_names = []
+        self.monochrome_channels = []
+        self.monochrome_colors = []
+        self.num_z = self.num_c = self.num_t = 1
+        self.input_height = self.input_width = 0
+        self.num_pyramid_levels = 5
+        self.flatfields = {}
+        self.acquisition_metadata = {}
+        self.dtype = np.uint16
+        self.chunks = None
+        self.h_shift = (0, 0)
+        if self.scan_pattern == 'S-Pattern':
+            self.h_shift_rev = (0, 0)
+            self.h_shift_rev_odd = 0
+        self.v_shift = (0, 0)
+        self.x_positions = set()
+        self.y_positions = set()
+        self._region_index: Dict[tuple, Dict[tuple, dict]] = {}
+
+    @property
+    def device(self):
+        import torch
+        if self._device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("Stitcher needs an MI355X (torch.cuda is not available); there is no CPU path")
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        return self._device
+
+    # --------------------------------------------------------------- metadata
+    def get_timepoints(self):
+        """(stitcher.py:121-124)"""
+        self.timepoints = [d for d in os.listdir(self.input_folder)
+                           if os.path.isdir(os.path.join(self.input_folder, d)) and d.isdigit()]
+        self.timepoints.sort(key=int)
+        return self.timepoints
+
+    def extract_acquisition_parameters(self):
+        with open(os.path.join(self.input_folder, 'acquisition parameters.json'), 'r') as fh:
+            self.acquisition_params = json.load(fh)
+
+    def get_pixel_size(self):
+        """(stitcher.py:131-140)"""
+        ap = self.acquisition_params
+        obj_focal_length_mm = ap['objective']['tube_lens_f_mm'] / ap['objective']['magnification']
+        actual_mag = ap['tube_lens_mm'] / obj_focal_length_mm
+        self.pixel_binning = ap.get('pixel_binning', 1)
+        self.pixel_size_um = ap['sensor_pixel_size_um'] / actual_mag
+        print("pixel_size_um:", self.pixel_size_um)
+
+    @staticmethod
+    def _read_coordinates(path: str) -> Dict[tuple, Tuple[float, float, float]]:
+        """coordinates.csv -> {(region, fov, z): (x mm, y mm, z um)}, first row wins like
+        ``coord_row.iloc[0]`` (stitcher.py:176-186)."""
+        table: Dict[tuple, Tuple[float, float, float]] = {}
+        with open(path) as fh:
+            header = [h.strip() for h in fh.readline().rstrip('\n').split(',')]
+            col = {name: i for i, name in enumerate(header)}
+            for line in fh:
+                parts = line.rstrip('\n').split(',')
+                if len(parts) < len(header):
+                    continue
+                key = (parts[col['region']], int(parts[col['fov']]), int(parts[col['z_level']]))
+                if key not in table:
+                    table[key] = (float(parts[col['x (mm)']]), float(parts[col['y (mm)']]), float(parts[col['z (um)']]))
+        return table
+
+    def parse_acquisition_metadata(self):
+        """File names -> ``acquisition_metadata`` in sorted-filename order (stitcher.py:143-257)."""
+        self.acquisition_metadata = {}
+        self._region_index = {}
+        regions, channels = set(), set()
+        max_z = max_fov = 0
+        for timepoint in self.timepoints:
+            image_folder = os.path.join(self.input_folder, str(timepoint))
+            print(f"Processing timepoint {timepoint}, image folder: {image_folder}")
+            try:
+                coords = self._read_coordinates(os.path.join(image_folder, 'coordinates.csv'))
+            except FileNotFoundError:
+                print(f"Warning: coordinates.csv not found for timepoint {timepoint}")
+                continue
+            files = sorted(f for f in os.listdir(image_folder) if f.endswith(_IMAGE_EXT) and 'focus_camera' not in f)
+            for file in files:
+                parts = file.split('_', 3)
+                region, fov, z_level = parts[0], int(parts[1]), int(parts[2])
+                channel = os.path.splitext(parts[3])[0].replace("_", " ").replace("full ", "full_")
+                pos = coords.get((region, fov, z_level))
+                if pos is None:
+                    print(f"Warning: No coordinates for {file}")
+                    continue
+                key = (int(timepoint), region, fov, z_level, channel)
+                rec = {'filepath': os.path.join(image_folder, file), 'x': pos[0], 'y': pos[1], 'z': pos[2],
+                       'channel': channel, 'z_level': z_level, 'region': region, 'fov_idx': fov, 't': int(timepoint)}
+                self.acquisition_metadata[key] = rec
+                self._region_index.setdefault((int(timepoint), region), {})[key] = rec
+                regions.add(region)
+                channels.add(channel)
+                max_z = max(max_z, z_level)
+                max_fov = max(max_fov, fov)
+        self.regions = sorted(regions)
+        self.channel_names = sorted(channels)
+        self.num_t = len(self.timepoints)
+        self.num_z = max_z + 1
+        self.num_fovs_per_region = max_fov + 1
+        if not self.acquisition_metadata:
+            raise ValueError(f"No image files with coordinates found under {self.input_folder}")
+        first_key = next(iter(self.acquisition_metadata))
+        first = self.acquisition_metadata[first_key]
+        first_image = read_image(first['filepath'])
+        self.dtype = first_image.dtype.type
+        if first_image.ndim in (2, 3):
+            self.input_height, self.input_width = first_image.shape[:2]
+        else:
+            raise ValueError(f"Unexpected image shape: {first_image.shape}")
+        self.chunks = (1, 1, 1, 512, 512)
+        self.monochrome_channels = []
+        for channel in self.channel_names:
+            ck = (first['t'], first['region'], first['fov_idx'], first['z_level'], channel)
+            img = read_image(self.acquisition_metadata[ck]['filepath'])
+            if img.ndim == 3 and img.shape[2] == 3:
+                base = channel.split('_')[0]
+                self.monochrome_channels.extend([f"{base}_R", f"{base}_G", f"{base}_B"])
+            else:
+                self.monochrome_channels.append(channel)
+        self.num_c = len(self.monochrome_channels)
+        self.monochrome_colors = [self.get_channel_color(n) for n in self.monochrome_channels]
+        print(f"Regions: {self.regions}, Channels: {self.channel_names}")
+        print(f"FOV dimensions: {self.input_height}x{self.input_width}")
+        print(f"{self.num_z} Z levels, {self.num_t} Time points")
+        print(f"{self.num_c} Channels: {self.monochrome_channels}")
+
+    def get_region_data(self, t, region):
+        """(stitcher.py:260-280) -- served from an index built once instead of a full scan."""
+        data = self._region_index.get((int(t), region))
+        if not data:
+            raise ValueError(f"No data found for timepoint {int(t)}, region {region}")
+        return data
+
+    def get_channel_color(self, channel_name):
+        """(stitcher.py:282-296)"""
+        for key, color in (('405', 0x0000FF), ('488', 0x00FF00), ('561', 0xFFCF00), ('638', 0xFF0000),
+                           ('730', 0x770000), ('_B', 0x0000FF), ('_G', 0x00FF00), ('_R', 0xFF0000)):
+            if key in channel_name:
+                return color
+        return 0xFFFFFF
+
+    def get_rows_and_columns(self):
+        """(stitcher.py:1220-1223)"""
+        return sorted(set(r[0] for r in self.regions)), sorted(set(r[1:] for r in self.regions))
+
+    def get_tile(self, t, region, x, y, channel, z_level):
+        """(stitcher.py:526-542) -> numpy image or None."""
+        for value in self.get_region_data(int(t), str(region)).values():
+            if value['x'] == x and value['y'] == y and value['channel'] == channel and value['z_level'] == z_level:
+                try:
+                    return read_image(value['filepath'])
+                except FileNotFoundError:
+                    print(f"Warning: Tile file not found: {value['filepath']}")
+                    return None
+        print(f"Warning: No matching tile found for region {region}, x={x}, y={y}, channel={channel}, z={z_level}")
+        return None
+
+    # ------------------------------------------------------------- geometry
+    def _shifts(self) -> Shifts:
+        rev = getattr(self, 'h_shift_rev', None) if self.scan_pattern == 'S-Pattern' else None
+        return Shifts(tuple(self.h_shift), tuple(self.v_shift), None if rev is None else tuple(rev),
+                      int(getattr(self, 'h_shift_rev_odd', 0)))
+
+    def calculate_output_dimensions(self, timepoint, region):
+        """(width_pixels, height_pixels); also sets x/y_positions and num_pyramid_levels
+        (stitcher.py:298-354)."""
+        region_data = self.get_region_data(int(timepoint), region)
+        self.x_positions = sorted(set(v['x'] for v in region_data.values()))
+        self.y_positions = sorted(set(v['y'] for v in region_data.values()))
+        width_pixels, height_pixels = placement.canvas_size(
+            len(self.x_positions), len(self.y_positions), self.input_width, self.input_height,
+            use_registration=self.use_registration, shifts=self._shifts(),
+            xs=self.x_positions, ys=self.y_positions, pixel_size_um=self.pixel_size_um)
+        max_dimension = 1
+        if len(self.regions) > 1:
+            rows, columns = self.get_rows_and_columns()
+            max_dimension = max(len(rows), len(columns))
+        self.num_pyramid_levels = placement.pyramid_levels(width_pixels, height_pixels, max_dimension)
+        return width_pixels, height_pixels
+
+    # ---------------------------------------------------------- registration
+    def normalize_image(self, img):
+        """(stitcher.py:613-617), host arithmetic (debug / API parity; the device path fuses
+        this into the FFT load)."""
+        img = np.asarray(img)
+        img_min, img_max = img.min(), img.max()
+        with np.errstate(all='ignore'):
+            img_normalized = (img - img_min) / (img_max - img_min)
+            scale_factor = np.iinfo(self.dtype).max if np.issubdtype(self.dtype, np.integer) else 1
+            return (img_normalized * scale_factor).astype(self.dtype)
+
+    def _register_two(self, img_a, img_b, max_overlap, vertical: bool):
+        import torch
+        a, b = np.asarray(img_a), np.asarray(img_b)
+        if a.ndim != 2 or b.ndim != 2 or a.shape != b.shape:
+            raise ValueError("images must be same shape")
+        tiles = torch.from_numpy(np.ascontiguousarray(np.stack([a, b]))).to(self.device)
+        h, w = a.shape
+        make = registration.vertical_pair if vertical else registration.horizontal_pair
+        pair, n0, n1 = make(0, 1, h, w, int(max_overlap))
+        s, _, _ = registration.register_pairs(tiles, np.array([pair], dtype=native.PAIR_DTYPE), n0, n1, 10,
+                                              self.normalization)
+        return s[0], n0, n1
+
+    def calculate_horizontal_shift(self, img_left, img_right, max_overlap):
+        """(stitcher.py:500-511) -> (dy, dx) python ints."""
+        s, n0, n1 = self._register_two(img_left, img_right, max_overlap, vertical=False)
+        return registration.horizontal_shift_from(s, n1)
+
+    def calculate_vertical_shift(self, img_top, img_bot, max_overlap):
+        """(stitcher.py:513-524)"""
+        s, n0, n1 = self._register_two(img_top, img_bot, max_overlap, vertical=True)
+        return registration.vertical_shift_from(s, n0)
+
+    def calculate_shifts(self, t, region):
+        """Centre-pair registration (stitcher.py:422-498); sets h_shift / v_shift
+        [/ h_shift_rev / h_shift_rev_odd]."""
+        region_data = self.get_region_data(t, region)
+        x_positions = sorted(set(v['x'] for v in region_data.values()))
+        y_positions = sorted(set(v['y'] for v in region_data.values()))
+        self.h_shift = (0, 0)
+        self.v_shift = (0, 0)
+        if not self.registration_channel:
+            self.registration_channel = self.channel_names[0]
+        elif self.registration_channel not in self.channel_names:
+            print(f"Warning: Specified registration channel '{self.registration_channel}' not found. "
+                  f"Using {self.channel_names[0]}.")
+            self.registration_channel = self.channel_names[0]
+        self.calculate_output_dimensions(int(t), region)
+        max_x_overlap, max_y_overlap = placement.registration_crop_widths(
+            sorted(self.x_positions), sorted(self.y_positions), self.input_width, self.input_height,
+            self.pixel_size_um, self.pixel_binning)
+        print("objective calculated - vertical overlap:", max_y_overlap, ", horizontal overlap:", max_x_overlap)
+        cx, cy = (len(x_positions) - 1) // 2, (len(y_positions) - 1) // 2
+        center_x, center_y = x_positions[cx], y_positions[cy]
+        right_x = bottom_y = None
+        get = lambda x, y: self.get_tile(t, region, x, y, self.registration_channel, self.registration_z_level)
+        if cx + 1 < len(x_positions):
+            right_x = x_positions[cx + 1]
+            a, b = get(center_x, center_y), get(right_x, center_y)
+            if a is not None and b is not None:
+                self.h_shift = self.calculate_horizontal_shift(a, b, max_x_overlap)
+            else:
+                print(f"Warning: Missing tiles for horizontal shift calculation in region {region}.")
+        if cy + 1 < len(y_positions):
+            bottom_y = y_positions[cy + 1]
+            a, b = get(center_x, center_y), get(center_x, bottom_y)
+            if a is not None and b is not None:
+                self.v_shift = self.calculate_vertical_shift(a, b, max_y_overlap)
+            else:
+                print(f"Warning: Missing tiles for vertical shift calculation in region {region}.")
+        if self.scan_pattern == 'S-Pattern' and right_x and bottom_y:
+            a, b = get(center_x, bottom_y), get(right_x, bottom_y)
+            if a is not None and b is not None:
+                self.h_shift_rev = self.calculate_horizontal_shift(a, b, max_x_overlap)
+                self.h_shift_rev_odd = cy % 2 == 0
+                print(f"Bi-Directional Horizontal Shift - Reverse Horizontal: {self.h_shift_rev}")
+            else:
+                print(f"Warning: Missing tiles for reverse horizontal shift calculation in region {region}.")
+        print(f"Calculated Uni-Directional Shifts - Horizontal: {self.h_shift}, Vertical: {self.v_shift}")
+
+    # -------------------------------------------------------------- flatfield
+    def apply_flatfield_correction(self, tile, channel_idx):
+        """(stitcher.py:607-611) on one host tile through the device kernel."""
+        if channel_idx not in self.flatfields:
+            return tile
+        import torch
+        tile = np.ascontiguousarray(tile)
+        h, w = tile.shape
+        plan = self._plan_for(np.array([(0, 0, h, w, 0, 0)]), h, w, h, w, native.SQ_FUSE_OVERWRITE)
+        canvas = torch.empty((1, h, w), dtype=native.torch_dtype_of(tile.dtype), device=self.device)
+        flat = torch.from_numpy(np.ascontiguousarray(self.flatfields[channel_idx])).to(self.device)
+        native.fuse_planes(plan, torch.from_numpy(tile[None, None]).to(self.device), canvas, [flat])
+        return canvas[0].cpu().numpy()
+
+    def get_flatfields(self, progress_callback=None):
+        """The reference fits BaSiC on <= 48 random tiles per channel (stitcher.py:365-419).
+        basicpy/jax are absent offline, so the estimate here is a documented stand-in, NOT a
+        restatement (parity unpinned): per-channel mean of the sampled tiles,
+        box-smoothed, normalised to mean 1.  Flatfields assigned to ``self.flatfields`` by the
+        caller are left untouched."""
+        for channel in self.channel_names:
+            if self.monochrome_channels.count(channel) != 1:
+                continue
+            channel_index = self.monochrome_channels.index(channel)
+            if channel_index in self.flatfields:
+                continue
+            print(f"Calculating {channel} flatfield...")
+            images = []
+            for t in self.timepoints:
+                paths = [v['filepath'] for k, v in self.acquisition_metadata.items()
+                         if v['channel'] == channel and k[0] == int(t)]
+                random.shuffle(paths)
+                images.extend(paths[:min(32, len(paths))])
+                if len(images) > 48:
+                    break
+            if not images:
+                print(f"WARNING: No images found for channel {channel} across all timepoints")
+                continue
+            acc = np.zeros((self.input_height, self.input_width), dtype=np.float64)
+            for p in images:
+                acc += read_image(p)
+            acc /= len(images)
+            k = max(1, min(self.input_height, self.input_width) // 16)
+            csum = np.cumsum(np.cumsum(np.pad(acc, ((k, k), (k, k)), mode='edge'), 0), 1)
+            csum = np.pad(csum, ((1, 0), (1, 0)))
+            n = 2 * k + 1
+            smooth = (csum[n:, n:] - csum[:-n, n:] - csum[n:, :-n] + csum[:-n, :-n]) / (n * n)
+            self.flatfields[channel_index] = (smooth / smooth.mean()).astype(np.float32)
+            if progress_callback:
+                progress_callback(channel_index + 1, self.num_c)
+
+    # ----------------------------------------------------------------- fusion
+    def _plan_for(self, rects, tile_h, tile_w, canvas_h, canvas_w, mode) -> native.FusePlan:
+        rects = np.asarray(rects, dtype=np.int64).reshape(-1, 6)
+        key = (rects.tobytes(), tile_h, tile_w, canvas_h, canvas_w, mode)
+        plan = self._plan_cache.get(key)
+        if plan is None:
+            if len(self._plan_cache) > 16:
+                self._plan_cache.clear()
+            plan = self._plan_cache[key] = native.FusePlan(rects, tile_h, tile_w, canvas_h, canvas_w, mode)
+        return plan
+
+    def _tile_rect(self, tile_info):
+        """sq_rect of one file: placement (stitcher.py:656-679) + crop (:570-587)."""
+        if self.use_registration:
+            col = self.x_positions.index(tile_info['x'])
+            row = self.y_positions.index(tile_info['y'])
+            self.col_index, self.row_index = col, row
+            return placement.registered_rect(row, col, len(self.y_positions), len(self.x_positions),
+                                             self.input_width, self.input_height, self._shifts(),
+                                             crop=self.fusion_mode == 'overwrite')
+        return placement.coordinate_rect(tile_info['x'], tile_info['y'], min(self.x_positions), min(self.y_positions),
+                                         self.input_width, self.input_height, self.pixel_size_um)
+
+    def init_output(self, timepoint, region):
+        """Device canvas (1, C, Z, Hc, Wc) (stitcher.py:356-362).  Not zero-filled: the fusion
+        kernel writes every voxel, zeros included."""
+        import torch
+        width, height = self.calculate_output_dimensions(timepoint, region)
+        shape = (1, self.num_c, self.num_z, height, width)
+        print(f"region {region} timepoint {timepoint} output array dimensions: {shape}")
+        return torch.empty(shape, dtype=native.torch_dtype_of(self.dtype), device=self.device)
+
+    def stitch_region(self, timepoint, region, progress_callback=None, device_output: bool = False):
+        """Fuse one (timepoint, region) -> 5-D TCZYX array of the input dtype
+        (stitcher.py:639-689).  Returns numpy (host) unless ``device_output``."""
+        import torch
+        start_time = time.time()
+        region_data = self.get_region_data(int(timepoint), region)
+        canvas = self.init_output(timepoint, region)
+        hc, wc = int(canvas.shape[3]), int(canvas.shape[4])
+        th, tw = self.input_height, self.input_width
+        total_tiles = len(region_data)
+        print(f"Beginning stitching of {total_tiles} tiles for region {region} timepoint {timepoint}")
+
+        # group the files by (channel, z) plane, keeping the reference's write order inside a plane
+        planes: Dict[int, List[Tuple[dict, int, tuple]]] = {}
+        for key, info in region_data.items():
+            _, _, fov, z_level, channel = key
+            rect = self._tile_rect(info)
+            if channel in self.monochrome_channels:
+                planes.setdefault(self.monochrome_channels.index(channel) * self.num_z + z_level, []).append((info, -1, rect))
+            else:   # RGB file -> three monochrome channels (stitcher.py:551-556)
+                base = channel.split('_')[0]
+                for i, color in enumerate('RGB'):
+                    ci = self.monochrome_channels.index(f"{base}_{color}")
+                    planes.setdefault(ci * self.num_z + z_level, []).append((info, i, rect))
+
+        mode = native.SQ_FUSE_OVERWRITE if self.fusion_mode == 'overwrite' else native.SQ_FUSE_FEATHER
+        flat_canvas = canvas.view(self.num_c * self.num_z, hc, wc)
+        # planes no file touches still have to come out as zeros
+        empty = [p for p in range(self.num_c * self.num_z) if p not in planes]
+        if empty:
+            zplan = self._plan_for(np.zeros((0, 6)), th, tw, hc, wc, native.SQ_FUSE_OVERWRITE)
+            for p in empty:
+                native.fuse_planes(zplan, torch.empty((1, 0, th, tw), dtype=canvas.dtype, device=self.device),
+                                   flat_canvas[p:p + 1])
+        flats_dev = {}
+        if self.apply_flatfield:
+            for ci, ff in self.flatfields.items():
+                flats_dev[ci] = torch.from_numpy(np.ascontiguousarray(ff)).to(self.device)
+
+        # batch planes that share one rectangle list (normally: all of them)
+        groups: Dict[bytes, List[int]] = {}
+        rect_of: Dict[bytes, np.ndarray] = {}
+        for p, items in planes.items():
+            r = np.array([it[2] for it in items], dtype=np.int64).reshape(-1, 6)
+            groups.setdefault(r.tobytes(), []).append(p)
+            rect_of[r.tobytes()] = r
+        free_bytes = torch.cuda.mem_get_info(self.device)[0]
+        processed = 0
+        pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
+        try:
+            for sig, plist in groups.items():
+                rects = rect_of[sig]
+                n = len(rects)
+                plan = self._plan_for(rects, th, tw, hc, wc, mode)
+                per_plane = n * th * tw * np.dtype(self.dtype).itemsize
+                batch = max(1, min(len(plist), int(free_bytes * 0.5) // max(1, per_plane)))
+                for b0 in range(0, len(plist), batch):
+                    chunk = plist[b0:b0 + batch]
+                    contiguous = all(chunk[i] + 1 == chunk[i + 1] for i in range(len(chunk) - 1))
+                    host = np.empty((len(chunk), n, th, tw), dtype=self.dtype)
+
+                    def load(job):
+                        pi, ti, (info, rgb, _) = job
+                        img = read_image(info['filepath'])
+                        if rgb >= 0:
+                            img = img[:, :, rgb]
+                        elif img.ndim == 3 and img.shape[0] == 1:
+                            img = img[0]
+                        if img.shape != (th, tw):
+                            raise ValueError(f"Unexpected tile shape: {img.shape}")
+                        host[pi, ti] = img
+
+                    jobs = [(pi, ti, it) for pi, p in enumerate(chunk) for ti, it in enumerate(planes[p])]
+                    for _ in pool.map(load, jobs):
+                        processed += 1
+                        if progress_callback:
+                            progress_callback(processed - 1, total_tiles)
+                    tiles = torch.from_numpy(host).to(self.device)
+                    flats = [flats_dev.get(p // self.num_z) for p in chunk] if self.apply_flatfield else None
+                    if contiguous:
+                        native.fuse_planes(plan, tiles, flat_canvas[chunk[0]:chunk[0] + len(chunk)], flats)
+                    else:
+                        for pi, p in enumerate(chunk):
+                            native.fuse_planes(plan, tiles[pi:pi + 1], flat_canvas[p:p + 1],
+                                               None if flats is None else flats[pi:pi + 1])
+        finally:
+            pool.shutdown(wait=True)
+        torch.cuda.synchronize(self.device)
+        print(f"Time to stitch region {region} timepoint {timepoint}: {time.time() - start_time}")
+        return canvas if device_output else canvas.cpu().numpy()
+
+    # ------------------------------------------------------------------ output
+    def save_region_ome_zarr(self, timepoint, region, stitched_region):
+        """(stitcher.py:771-859) via the package-free writer in omezarr.py."""
+        if hasattr(stitched_region, 'cpu'):
+            stitched_region = stitched_region.cpu().numpy()
+        output_path = os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched.ome.zarr")
+        os.makedirs(os.path.dirname(output_path), exist_ok=True)
+        dz_um = float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
+        write_ome_zarr(output_path, np.asarray(stitched_region), pixel_size_um=self.pixel_size_um, dz_um=dz_um,
+                       channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
+                       num_levels=self.num_pyramid_levels, chunks=self.chunks or (1, 1, 1, 512, 512),
+                       name=f"{region}_t{timepoint}")
+        return output_path
+
+    def save_region_aics(self, timepoint, region, stitched_region):
+        """OME-TIFF output (stitcher.py:691-769) needs aicsimageio, which is not part of the hot
+        path and not available offline."""
+        raise NotImplementedError("'.ome.tiff' output is outside the hot-path scope (SURVEY.md 8f); use '.ome.zarr'")
+
+    # --------------------------------------------------------------------- run
+    def run(self):
+        """(stitcher.py:1226-1299): metadata, [flatfields], [shifts once], then every
+        timepoint x region: stitch + save."""
+        stime = time.time()
+        self.get_timepoints()
+        self.extract_acquisition_parameters()
+        self.get_pixel_size()
+        self.parse_acquisition_metadata()
+        os.makedirs(self.output_folder, exist_ok=True)
+        if self.apply_flatfield:
+            print("Calculating flatfields...")
+            self.getting_flatfields.emit()
+            self.get_flatfields(progress_callback=self.update_progress.emit)
+            print("Time to calculate flatfields:", time.time() - stime)
+        if self.use_registration:
+            print(f"\nCalculating shifts on region {self.regions[0]}...")
+            self.calculate_shifts(self.timepoints[0], self.regions[0])
+        output_path = None
+        for timepoint in self.timepoints:
+            timepoint = int(timepoint)
+            ttime = time.time()
+            print(f"\nProcessing timepoint {timepoint}")
+            os.makedirs(os.path.join(self.output_folder, f"{timepoint}_stitched"), exist_ok=True)
+            for region in self.regions:
+                rtime = time.time()
+                print(f"Processing region {region}...")
+                self.starting_stitching.emit()
+                stitched_region = self.stitch_region(timepoint, region, progress_callback=self.update_progress.emit)
+                self.starting_saving.emit(False)
+                if self.output_format.endswith('.zarr'):
+                    output_path = self.save_region_ome_zarr(timepoint, region, stitched_region)
+                else:
+                    output_path = self.save_region_aics(timepoint, region, stitched_region)
+                print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
+            print(f"Completed timepoint {timepoint}: {time.time() - ttime}")
+        self.starting_saving.emit(True)
+        if self.merge_timepoints or self.merge_hcs_regions:
+            print("Note: merging timepoints / HCS regions is an output-format step outside the hot-path scope; "
+                  "per-(timepoint, region) stores were written.")
+        final_path = os.path.join(self.output_folder, f"{self.timepoints[-1]}_stitched",
+                                  f"{self.regions[-1]}_stitched{self.output_format}")
+        self.finished_saving.emit(final_path, self.dtype)
+        print(f"Total processing time: {time.time() - stime}")

@@ -1,0 +1,146 @@
+"""Host logic that needs no GPU: parameters, CLI flag surface, placement geometry against the
+oracle and the golden placements, metadata parsing, TIFF and OME-Zarr round trips."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import REGION_CASES, load_case, spec_of
+from image_stitcher_amd import omezarr, placement, synth, tiffio
+from image_stitcher_amd.stitcher_parameters import StitchingParameters
+from image_stitcher_amd import stitcher_cli
+from oracle import stitch_oracle as O
+
+
+def test_parameters_validation_and_json(tmp_path):
+    p = StitchingParameters(input_folder=str(tmp_path), use_registration=True, registration_channel=None)
+    p.validate()
+    assert p.registration_channel == ''
+    assert p.stitched_folder.startswith(str(tmp_path) + "_stitched_")
+    j = tmp_path / 'p.json'
+    p.to_json(str(j))
+    q = StitchingParameters.from_json(str(j))
+    assert q.to_dict() == p.to_dict()
+    assert StitchingParameters.from_dict({'input_folder': str(tmp_path), 'bogus': 1}).input_folder == str(tmp_path)
+    with pytest.raises(ValueError, match='does not exist'):
+        StitchingParameters(input_folder=str(tmp_path / 'nope')).validate()
+    with pytest.raises(ValueError, match='Output format'):
+        StitchingParameters(input_folder=str(tmp_path), output_format='.png').validate()
+    with pytest.raises(ValueError, match='Scan pattern'):
+        StitchingParameters(input_folder=str(tmp_path), scan_pattern='Zigzag').validate()
+    with pytest.raises(ValueError, match='non-negative'):
+        StitchingParameters(input_folder=str(tmp_path), use_registration=True, registration_z_level=-1).validate()
+
+
+def test_cli_flags_match_reference(tmp_path):
+    a = stitcher_cli.parse_args(['-i', str(tmp_path), '-r', '-ff', '--registration-channel', '488',
+                                 '--registration-z-level', '2', '-s', 'S-Pattern', '-mt', '-mw', '-f', '.ome.zarr',
+                                 '--dynamic-registration'])
+    p = stitcher_cli.create_params(a)
+    assert (p.use_registration, p.apply_flatfield, p.registration_channel, p.registration_z_level) == (True, True, '488', 2)
+    assert (p.scan_pattern, p.merge_timepoints, p.merge_hcs_regions, p.dynamic_registration) == ('S-Pattern', True, True, True)
+    with pytest.raises(SystemExit):
+        stitcher_cli.parse_args([])   # -i is required
+
+
+def test_tiff_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    for arr in (rng.integers(0, 65536, (33, 47)).astype(np.uint16), rng.integers(0, 256, (20, 31)).astype(np.uint8),
+                rng.integers(0, 256, (12, 9, 3)).astype(np.uint8)):
+        p = str(tmp_path / 'a.tiff')
+        tiffio.write_tiff(p, arr)
+        np.testing.assert_array_equal(tiffio.read_image(p), arr)
+    with pytest.raises(ValueError):
+        tiffio.write_tiff(str(tmp_path / 'b.tiff'), np.zeros((4, 4), np.float32))
+
+
+def test_omezarr_roundtrip(tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 65536, (1, 2, 3, 700, 530)).astype(np.uint16)
+    img[0, 1, 2] = 0    # an all-zero plane is not written (fill_value)
+    path = omezarr.write_ome_zarr(str(tmp_path / 'r.ome.zarr'), img, pixel_size_um=0.5, dz_um=1.5,
+                                  channel_names=['a 405', 'b 488'], channel_colors=[0xFF, 0xFF00], num_levels=3)
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '0')), img)
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '1')), img[..., ::2, ::2])
+    with open(os.path.join(path, '.zattrs')) as fh:
+        attrs = json.load(fh)
+    ms = attrs['multiscales'][0]
+    assert [a['name'] for a in ms['axes']] == ['t', 'c', 'z', 'y', 'x']
+    assert ms['datasets'][2]['coordinateTransformations'][0]['scale'] == [1, 1, 1.5, 2.0, 2.0]
+    assert [c['label'] for c in attrs['omero']['channels']] == ['a 405', 'b 488']
+
+
+@pytest.mark.parametrize('name', REGION_CASES)
+def test_placement_matches_golden_and_oracle(name):
+    """Product geometry (placement.py) == reference placements recorded in the fixtures."""
+    info, arrays = load_case(name)
+    spec = spec_of(info)
+    p = info['params']
+    shifts = placement.Shifts()
+    if p['use_registration']:
+        shifts = placement.Shifts(tuple(info['h_shift']), tuple(info['v_shift']),
+                                  tuple(info['h_shift_rev']) if 'h_shift_rev' in info else None,
+                                  info.get('h_shift_rev_odd', 0))
+    xs = sorted(set(spec.stage_mm(0, c)[0] for c in range(spec.cols)))
+    ys = sorted(set(spec.stage_mm(r, 0)[1] for r in range(spec.rows)))
+    wc, hc = placement.canvas_size(spec.cols, spec.rows, spec.tile_w, spec.tile_h,
+                                   use_registration=p['use_registration'], shifts=shifts, xs=xs, ys=ys,
+                                   pixel_size_um=spec.pixel_size_um)
+    for key, cinfo in info['canvases'].items():
+        assert cinfo['shape'][3:] == [hc, wc]
+        gold = arrays[f'{key}_placements']          # (c, z, x_pixel, y_pixel, row, col) BEFORE the crop offset
+        for c, z, x_px, y_px, row, col in gold:
+            if p['use_registration']:
+                sy, sx, h, w, dy, dx = placement.registered_rect(int(row), int(col), spec.rows, spec.cols,
+                                                                 spec.tile_w, spec.tile_h, shifts)
+                assert (dy - sy, dx - sx) == (y_px, x_px)
+        if not p['use_registration']:
+            # coordinate mode: rebuild from stage positions in sorted-filename order
+            fovs = [spec.fov_index(r, c) for r in range(spec.rows) for c in range(spec.cols)]
+            order = placement.filename_order(fovs)
+            per_plane = gold[(gold[:, 0] == 0) & (gold[:, 1] == 0)]
+            for k, i in enumerate(order):
+                r, c = divmod(i, spec.cols)
+                x_mm, y_mm = spec.stage_mm(r, c)
+                rect = placement.coordinate_rect(x_mm, y_mm, min(xs), min(ys), spec.tile_w, spec.tile_h, spec.pixel_size_um)
+                assert (rect[5], rect[4]) == (per_plane[k][2], per_plane[k][3])
+
+
+def test_crop_origins_and_widths():
+    spec = synth.GridSpec(rows=2, cols=2, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244)
+    xs = [spec.stage_mm(0, c)[0] for c in range(2)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(2)]
+    assert placement.registration_crop_widths(xs, ys, 2048, 2048, spec.pixel_size_um, 2) == \
+        O.max_overlaps(xs, ys, 2048, 2048, spec.pixel_size_um, 2) == (256, 256)
+    assert placement.horizontal_crop_origins(2048, 2048, 256) == (1024, 256, (512, 1792), (512, 0))
+    assert placement.vertical_crop_origins(2048, 2048, 256) == (256, 1024, (1792, 512), (0, 512))
+    a = np.arange(100 * 90).reshape(100, 90)
+    n0, n1, (ry, rx), (my, mx) = placement.horizontal_crop_origins(100, 90, 30)
+    ra, rb = O.overlap_crops_horizontal(a, a, 30)
+    np.testing.assert_array_equal(a[ry:ry + n0, rx:rx + n1], ra)
+    np.testing.assert_array_equal(a[my:my + n0, mx:mx + n1], rb)
+    n0, n1, (ry, rx), (my, mx) = placement.vertical_crop_origins(100, 90, 30)
+    ra, rb = O.overlap_crops_vertical(a, a, 30)
+    np.testing.assert_array_equal(a[ry:ry + n0, rx:rx + n1], ra)
+    np.testing.assert_array_equal(a[my:my + n0, mx:mx + n1], rb)
+    with pytest.raises(ValueError, match='same shape'):
+        placement.horizontal_crop_origins(100, 90, 0)      # [-0:] vs [:0]: the reference fails inside skimage
+
+
+def test_stitcher_refuses_to_run_without_gpu(tmp_path):
+    import torch
+    from image_stitcher_amd.stitcher import Stitcher
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    spec = synth.GridSpec(rows=2, cols=2, tile_h=32, tile_w=32, ov_y=8, ov_x=8)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    st = Stitcher(StitchingParameters(input_folder=root))
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    assert st.regions == ['R0'] and st.num_z == 1 and (st.input_height, st.input_width) == (32, 32)
+    xs = [spec.stage_mm(0, c)[0] for c in range(2)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(2)]
+    assert st.calculate_output_dimensions(0, 'R0') == O.output_dimensions(xs, ys, 32, 32, spec.pixel_size_um, False)[:2]
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        st.stitch_region(0, 'R0')

@@ -1,0 +1,112 @@
+"""End-to-end parity: the drop-in ``Stitcher`` on the GPU against canvases, shifts and
+placements produced by the unmodified reference (tests/golden/*.npz|json)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import REGION_CASES, flatfields_for, load_case, sha, spec_of
+from image_stitcher_amd import omezarr, synth
+from image_stitcher_amd.stitcher import Stitcher
+from image_stitcher_amd.stitcher_parameters import StitchingParameters
+from image_stitcher_amd import stitcher_cli
+
+pytestmark = pytest.mark.gpu
+
+
+def _prepared(info, root, normalization):
+    p = info['params']
+    params = StitchingParameters(input_folder=root, use_registration=p['use_registration'],
+                                 apply_flatfield=p['apply_flatfield'],
+                                 registration_channel=p['registration_channel'],
+                                 registration_z_level=p['registration_z_level'],
+                                 scan_pattern=info['spec']['scan_pattern'])
+    st = Stitcher(params, normalization=normalization)
+    st.get_timepoints()
+    st.extract_acquisition_parameters()
+    st.get_pixel_size()
+    st.parse_acquisition_metadata()
+    flats = flatfields_for(info, st.num_c)
+    if flats:
+        st.flatfields = flats
+    return st
+
+
+@pytest.mark.parametrize('name', REGION_CASES)
+def test_stitcher_matches_reference(name, tmp_path):
+    info, arrays = load_case(name)
+    spec = spec_of(info)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    st = _prepared(info, root, normalization=None)     # golden shifts come from scikit-image 0.18.3
+    assert st.regions == info['regions'] and st.monochrome_channels == info['channels']
+    assert st.num_z == info['num_z'] and str(np.dtype(st.dtype)) == info['dtype']
+    if info['params']['use_registration']:
+        st.calculate_shifts(st.timepoints[0], st.regions[0])
+        assert list(st.h_shift) == info['h_shift'] and list(st.v_shift) == info['v_shift']
+        if spec.scan_pattern == 'S-Pattern':
+            assert list(st.h_shift_rev) == info['h_shift_rev']
+            assert int(st.h_shift_rev_odd) == info['h_shift_rev_odd']
+        # the scikit-image >= 0.19 default recovers the same integers on these scenes
+        st2 = _prepared(info, root, normalization='phase')
+        st2.calculate_shifts(st2.timepoints[0], st2.regions[0])
+        assert (list(st2.h_shift), list(st2.v_shift)) == (info['h_shift'], info['v_shift'])
+    for key, cinfo in info['canvases'].items():
+        t, region = key[1:].split('_', 1)
+        canvas = st.stitch_region(int(t), region)
+        assert list(canvas.shape) == cinfo['shape']
+        assert st.num_pyramid_levels == cinfo['num_pyramid_levels']
+        assert sha(canvas) == cinfo['sha256']
+        if f'{key}_canvas' in arrays:
+            np.testing.assert_array_equal(canvas, arrays[f'{key}_canvas'])
+        for wi, (c, z, y0, x0, hh, ww) in enumerate(cinfo.get('windows', [])):
+            np.testing.assert_array_equal(canvas[0, c, z, y0:y0 + hh, x0:x0 + ww], arrays[f'{key}_win{wi}'])
+
+
+def test_single_tile_methods_match_golden(tmp_path):
+    v = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'flatfield_vectors.npz'))
+    spec = synth.GridSpec(rows=1, cols=1, tile_h=48, tile_w=64, ov_y=0, ov_x=0, seed=77)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    st = Stitcher(StitchingParameters(input_folder=root, apply_flatfield=True))
+    for dt in ('float32', 'float64'):
+        st.flatfields = {0: v[f'ff_{dt}']}
+        np.testing.assert_array_equal(st.apply_flatfield_correction(v['tile'], 0), v[f'out_{dt}'])
+    tile = v['tile']
+    assert st.apply_flatfield_correction(tile, 3) is tile
+    n = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'normalize_vectors.npz'))
+    np.testing.assert_array_equal(st.normalize_image(n['in_uint16']), n['out_uint16'])
+
+
+def test_cli_end_to_end_writes_ome_zarr(tmp_path, capsys):
+    info, arrays = load_case('reg_3x4_small')
+    spec = spec_of(info)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    stitcher_cli.main(['-i', root, '-r', '--registration-channel', info['params']['registration_channel'],
+                       '--registration-z-level', '1', '--normalization', 'none'])
+    out_dirs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
+    assert len(out_dirs) == 1
+    store = os.path.join(tmp_path, out_dirs[0], '0_stitched', 'R0_stitched.ome.zarr')
+    got = omezarr.read_array(os.path.join(store, '0'))
+    np.testing.assert_array_equal(got, arrays['t0_R0_canvas'])
+    # bad input folder: message on stderr, exit code 1 (stitcher_cli.py:114-116)
+    with pytest.raises(SystemExit) as e:
+        stitcher_cli.main(['-i', str(tmp_path / 'missing')])
+    assert e.value.code == 1
+    assert 'Error: Input folder does not exist' in capsys.readouterr().err
+
+
+def test_feather_mode_runs_and_agrees_with_overwrite_away_from_seams(tmp_path):
+    info, arrays = load_case('reg_neg_skew')
+    spec = spec_of(info)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    st = _prepared(info, root, 'phase')
+    st.fusion_mode = 'feather'
+    st.calculate_shifts(0, 'R0')
+    canvas = st.stitch_region(0, 'R0')
+    ref = arrays['t0_R0_canvas']
+    assert canvas.shape == ref.shape
+    # tile interiors (covered by one tile only) are identical in both modes
+    np.testing.assert_array_equal(canvas[0, 0, 0, 50:80, 50:80], ref[0, 0, 0, 50:80, 50:80])
