@@ -260,26 +260,40 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
     _check(L.sq_fuse_planes(C.byref(a), _stream_ptr(stream)), 'sq_fuse_planes')
 
 
-def tile_minmax(tiles, stream=None):
-    """Per-tile (min, max) of a contiguous device stack [N, H, W] -> device int32 tensor [N, 2]
-    (values are uint32 on the C side; they fit int32 for uint8/uint16 tiles)."""
+def _tile_table(tiles, tile_ptrs, shape, np_dtype):
+    """(ptrs_dev, base_dev, stride, n, h, w, sq dtype) for a stack [N, H, W] or a pointer table."""
+    if tile_ptrs is not None:
+        n = int(tile_ptrs.numel())
+        h, w = (int(v) for v in shape)
+        return tile_ptrs.data_ptr(), None, 0, n, h, w, sq_dtype_of(np_dtype)
+    n, h, w = (int(v) for v in tiles.shape)
+    return None, tiles.data_ptr(), h * w, n, h, w, sq_dtype_of(np_dtype_of_torch(tiles.dtype))
+
+
+def tile_minmax(tiles, stream=None, tile_ptrs=None, shape=None, np_dtype=None):
+    """Per-tile (min, max) of a contiguous device stack [N, H, W] (or of the dense H x W tiles a
+    device int64 pointer table names) -> device int32 tensor [N, 2] (uint32 on the C side; the
+    values fit int32 for uint8/uint16 tiles)."""
     import torch
     L = lib()
-    n, h, w = (int(v) for v in tiles.shape)
-    out = torch.empty((n, 2), dtype=torch.int32, device=tiles.device)
-    _check(L.sq_tile_minmax(None, tiles.data_ptr(), h * w, n, h, w, w,
-                            sq_dtype_of(np_dtype_of_torch(tiles.dtype)), out.data_ptr(), _stream_ptr(stream)),
+    ptrs, base, stride, n, h, w, dt = _tile_table(tiles, tile_ptrs, shape, np_dtype)
+    device = tile_ptrs.device if tile_ptrs is not None else tiles.device
+    out = torch.empty((n, 2), dtype=torch.int32, device=device)
+    _check(L.sq_tile_minmax(ptrs, base, stride, n, h, w, w, dt, out.data_ptr(), _stream_ptr(stream)),
            'sq_tile_minmax')
     return out
 
 
 def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
-                   normalization: int = SQ_NORM_PHASE, stream=None) -> np.ndarray:
-    """Batched phase cross-correlation of crop pairs.  ``tiles`` [N, H, W] device stack,
-    ``pairs`` PAIR_DTYPE host array.  Returns a RESULT_DTYPE host array (synchronises)."""
+                   normalization: int = SQ_NORM_PHASE, stream=None, tile_ptrs=None, shape=None,
+                   np_dtype=None) -> np.ndarray:
+    """Batched phase cross-correlation of crop pairs.  ``tiles`` [N, H, W] device stack (or a
+    pointer table + shape + dtype), ``pairs`` PAIR_DTYPE host array.  Returns a RESULT_DTYPE host
+    array (synchronises)."""
     import torch
     L = lib()
-    n, h, w = (int(v) for v in tiles.shape)
+    ptrs, base, stride, n, h, w, dt = _tile_table(tiles, tile_ptrs, shape, np_dtype)
+    device = tile_ptrs.device if tile_ptrs is not None else tiles.device
     pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
     npairs = len(pairs)
     out = np.zeros(npairs, dtype=RESULT_DTYPE)
@@ -288,15 +302,23 @@ def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_
     ws_bytes = L.sq_register_workspace_bytes(npairs, n0, n1, upsample_factor)
     if ws_bytes < 0:
         raise NativeError(f"sq_register_workspace_bytes failed: {L.sq_last_error().decode()}")
-    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=tiles.device)
-    pairs_dev = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(tiles.device)
-    res_dev = torch.zeros(npairs * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=tiles.device)
+    if len(pairs) and (min(pairs['ref_tile'].min(), pairs['mov_tile'].min()) < 0 or
+                       max(pairs['ref_tile'].max(), pairs['mov_tile'].max()) >= n):
+        raise ValueError("pair refers to a tile outside the table")
+    if len(pairs) and ((pairs['ref_y0'] < 0).any() or (pairs['ref_x0'] < 0).any() or (pairs['mov_y0'] < 0).any()
+                       or (pairs['mov_x0'] < 0).any() or (pairs['ref_y0'] + n0 > h).any()
+                       or (pairs['mov_y0'] + n0 > h).any() or (pairs['ref_x0'] + n1 > w).any()
+                       or (pairs['mov_x0'] + n1 > w).any()):
+        raise ValueError("crop reaches outside its tile")
+    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=device)
+    pairs_dev = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(device)
+    res_dev = torch.zeros(npairs * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
     a = _RegisterArgs()
-    a.tile_ptrs_dev = None
-    a.tile_base_dev = tiles.data_ptr()
-    a.tile_stride = h * w
+    a.tile_ptrs_dev = ptrs
+    a.tile_base_dev = base
+    a.tile_stride = stride
     a.n_tiles, a.tile_h, a.tile_w, a.tile_pitch = n, h, w, w
-    a.tile_dtype = sq_dtype_of(np_dtype_of_torch(tiles.dtype))
+    a.tile_dtype = dt
     a.minmax_dev = minmax.data_ptr()
     a.pairs_dev = pairs_dev.data_ptr()
     a.n_pairs = npairs

@@ -98,34 +98,52 @@ def vertical_shift_from(shift: np.ndarray, n0: int) -> Tuple[int, int]:
 
 def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], ys: Sequence[float],
                          pixel_size_um: float, pixel_binning: int, normalization='phase',
-                         scan_pattern: str = 'Unidirectional', tile_index=None, minmax=None) -> Shifts:
+                         scan_pattern: str = 'Unidirectional', tile_index=None) -> Shifts:
     """calculate_shifts (stitcher.py:422-498) on a device stack of one (channel, z) plane.
 
     ``tile_index(row, col) -> index into tiles`` (default row-major).  Picks the centre tile
-    and its right / bottom neighbours; S-Pattern adds the pair one row below."""
+    and its right / bottom neighbours; S-Pattern adds the pair one row below.  Only the tiles
+    involved are touched (min/max included), like the reference's get_tile calls."""
     height, width = int(tiles.shape[-2]), int(tiles.shape[-1])
     idx = tile_index or (lambda r, c: r * n_cols + c)
     mx, my = placement.registration_crop_widths(xs, ys, width, height, pixel_size_um, pixel_binning)
     ci, ri = (n_cols - 1) // 2, (n_rows - 1) // 2
     out = Shifts()
-    if minmax is None:
-        minmax = native.tile_minmax(tiles)
-    hp = []
+    hp, vp = [], []
     if ci + 1 < n_cols:
-        p, n0, n1 = horizontal_pair(idx(ri, ci), idx(ri, ci + 1), height, width, mx)
-        hp.append(p)
+        hp.append((idx(ri, ci), idx(ri, ci + 1)))
         if scan_pattern == 'S-Pattern' and ri + 1 < n_rows:
-            hp.append(horizontal_pair(idx(ri + 1, ci), idx(ri + 1, ci + 1), height, width, mx)[0])
-        s, _, _ = register_pairs(tiles, np.array(hp, dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+            hp.append((idx(ri + 1, ci), idx(ri + 1, ci + 1)))
+    if ri + 1 < n_rows:
+        vp.append((idx(ri, ci), idx(ri + 1, ci)))
+    used = sorted({t for p in hp + vp for t in p})
+    if not used:
+        return out
+    local = {t: i for i, t in enumerate(used)}
+    ptrs = native.pointer_table([tiles[t] for t in used], tiles.device)
+    np_dtype = native.np_dtype_of_torch(tiles.dtype)
+    minmax = native.tile_minmax(None, tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
+    code = _norm_code(normalization)
+
+    def run(pairs, make):
+        rows = []
+        for a, b in pairs:
+            p, n0, n1 = make(local[a], local[b], height, width, mx if make is horizontal_pair else my)
+            rows.append(p)
+        res = native.register_pairs(None, minmax, np.array(rows, dtype=native.PAIR_DTYPE), n0, n1, 10, code,
+                                    tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
+        return shifts_from_results(res, 10)[0], n0, n1
+
+    if hp:
+        s, n0, n1 = run(hp, horizontal_pair)
         out.h_shift = horizontal_shift_from(s[0], n1)
         if len(hp) > 1:
             out.h_shift_rev = horizontal_shift_from(s[1], n1)
             out.h_shift_rev_odd = int(ri % 2 == 0)
     if scan_pattern == 'S-Pattern' and out.h_shift_rev is None:
         out.h_shift_rev = (0, 0)
-    if ri + 1 < n_rows:
-        p, n0, n1 = vertical_pair(idx(ri, ci), idx(ri + 1, ci), height, width, my)
-        s, _, _ = register_pairs(tiles, np.array([p], dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+    if vp:
+        s, n0, n1 = run(vp, vertical_pair)
         out.v_shift = vertical_shift_from(s[0], n0)
     return out
 

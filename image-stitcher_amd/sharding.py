@@ -1,0 +1,72 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, no data-path collective.
+
+Fusion shards by output: every (timepoint, region, channel, z) plane is independent
+(reference precedent: per-FOV independent writes, zarr_stitcher.py:443-489), so planes (or whole
+regions) are dealt to ranks and never exchanged.  Registration shards by pair.  The only
+collective is an all-gather of the small shift table (RCCL over xGMI on the GPU box, gloo in
+the CPU tests): a few int32 per region, latency-bound.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .placement import Shifts
+
+SHIFT_ROW = 8   # valid, h_dy, h_dx, v_dy, v_dx, rev_dy, rev_dx, rev_odd  (rev_* = 0 and valid&2 unset without S-Pattern)
+
+
+def block_cyclic(n_items: int, rank: int, world: int) -> List[int]:
+    """Indices of the work items rank ``rank`` owns: i with i % world == rank."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return list(range(rank, n_items, world))
+
+
+def shifts_to_row(s: Optional[Shifts]) -> np.ndarray:
+    row = np.zeros(SHIFT_ROW, dtype=np.int32)
+    if s is None:
+        return row
+    row[0] = 1 | (2 if s.h_shift_rev is not None else 0)
+    row[1:3] = s.h_shift
+    row[3:5] = s.v_shift
+    if s.h_shift_rev is not None:
+        row[5:7] = s.h_shift_rev
+        row[7] = int(s.h_shift_rev_odd)
+    return row
+
+
+def row_to_shifts(row: Sequence[int]) -> Optional[Shifts]:
+    row = [int(v) for v in row]
+    if not row[0] & 1:
+        return None
+    rev = (row[5], row[6]) if row[0] & 2 else None
+    return Shifts((row[1], row[2]), (row[3], row[4]), rev, row[7])
+
+
+def all_gather_shift_table(local_rows: np.ndarray, device=None, group=None) -> np.ndarray:
+    """Every rank contributes ``local_rows`` [k, SHIFT_ROW] int32 (same k on every rank) and gets the
+    table [world * k, SHIFT_ROW] back, rank-major.  Single process: returns the input."""
+    import torch
+    import torch.distributed as dist
+    local_rows = np.ascontiguousarray(local_rows, dtype=np.int32).reshape(-1, SHIFT_ROW)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_rows.copy()
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(local_rows)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.cpu().numpy().reshape(-1, SHIFT_ROW)
+
+
+def first_valid(table: np.ndarray) -> Optional[Shifts]:
+    """The reference registers once and applies the result everywhere (stitcher.py:1244-1246):
+    the first valid row of the gathered table is that result."""
+    for row in table:
+        s = row_to_shifts(row)
+        if s is not None:
+            return s
+    return None
