@@ -207,25 +207,31 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth):
-    """The oracle (a numpy port of the reference path) on ONE (c, z) plane of the same workload:
-    registration of the two centre pairs + overwrite fusion of the plane's g*g tiles."""
+def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, max_planes=10):
+    """The oracle (a numpy port of the reference path) on a bounded sample of the same workload:
+    registration of the two centre pairs once (stitcher.py:1244-1246), then overwrite fusion of
+    up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work."""
     from image_stitcher_amd import placement
     from oracle import stitch_oracle as O
-    host = tiles[0].cpu().numpy()
-    flat = flat_list[0].cpu().numpy() if flat_list else None
+    n = min(max_planes, tiles.shape[0])
+    host = tiles[:n].cpu().numpy()
+    flats = [flat_list[p].cpu().numpy() if flat_list else None for p in range(n)]
     t0 = time.perf_counter()
     mx, my = O.max_overlaps(xs, ys, TILE, TILE, spec.pixel_size_um, spec.pixel_binning)
     ci = ri = (g - 1) // 2
-    h = O.calculate_horizontal_shift(host[ri * g + ci], host[ri * g + ci + 1], mx, np.uint16, 'phase')
-    v = O.calculate_vertical_shift(host[ri * g + ci], host[(ri + 1) * g + ci], my, np.uint16, 'phase')
+    h = O.calculate_horizontal_shift(host[0, ri * g + ci], host[0, ri * g + ci + 1], mx, np.uint16, 'phase')
+    v = O.calculate_vertical_shift(host[0, ri * g + ci], host[0, (ri + 1) * g + ci], my, np.uint16, 'phase')
     assert (tuple(h), tuple(v)) == (truth.h_shift, truth.v_shift)
     rects = placement.grid_rects(g, g, TILE, TILE, placement.Shifts(tuple(h), tuple(v)), order=order_rc)
-    plane = O.fuse_plane_overwrite([host[i] for i in order], rects, hc, wc, flat)
+    voxels = 0
+    for p in range(n):
+        plane = O.fuse_plane_overwrite([host[p, i] for i in order], rects, hc, wc, flats[p])
+        voxels += plane.size
+        del plane
     dt = time.perf_counter() - t0
-    return {'value': round(plane.size / dt / 1e6, 1), 'unit': 'Mvoxel/s', 'cores': 1, 'kind': 'port',
-            'sample': f'one (c,z) plane of the workload ({g}x{g} tiles -> {hc}x{wc} canvas), registration of the '
-                      f'2 centre pairs + fusion, numpy oracle, {dt:.1f} s on {os.cpu_count()} visible cores (1 used)'}
+    return {'value': round(voxels / dt / 1e6, 1), 'unit': 'Mvoxel/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} (c,z) planes of the workload ({g}x{g} tiles -> {hc}x{wc} canvas each): registration of '
+                      f'the 2 centre pairs once + fusion, numpy oracle, {dt:.1f} s, 1 of {os.cpu_count()} host cores used'}
 
 
 if __name__ == '__main__':

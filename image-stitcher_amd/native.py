@@ -88,6 +88,10 @@ def lib() -> C.CDLL:
             raise NativeError(
                 f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64.so.7; loading it first makes this library bind to
+        # the SAME HIP runtime (same SONAME) instead of bringing /opt/rocm's copy in beside it --
+        # two runtimes in one process cannot see each other's device allocations.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
