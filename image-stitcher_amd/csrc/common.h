@@ -57,12 +57,18 @@ struct Ref {
 };
 static_assert(sizeof(Ref) == 16, "Ref layout");
 
+// One unit of device work: up to BLOCK_ROWS x BLOCK_COLS of one span, self-contained so that a
+// workgroup needs ONE descriptor load before it can start streaming (no span/ref indirection).
+//   overwrite: nref in {0,1}; a = tile index, b/c = tile pixel (y, x) that lands on (dst_y, dst_x)
+//   feather  : a = first ref of the span, b/c = (row0, col0) of this block inside the span
 struct Item {
+    int32_t dst_y, dst_x;
+    int32_t hw;  // rows << 16 | cols
+    int32_t nref;
+    int32_t a, b, c;
     int32_t span;
-    int32_t row0, col0;  // block origin inside the span
-    int32_t pad;
 };
-static_assert(sizeof(Item) == 16, "Item layout");
+static_assert(sizeof(Item) == 32, "Item layout");
 
 }  // namespace sq
 

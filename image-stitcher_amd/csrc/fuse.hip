@@ -8,12 +8,17 @@
 // Roofline: HBM.  Algorithmic traffic is 2 B read + 2 B write per uint16 voxel (+ the flatfield,
 // which is re-used by every tile of a channel and lives in L2 / Infinity Cache).
 //
-// Mapping: grid = (work items, planes); one item = up to BLOCK_ROWS x BLOCK_COLS of one span;
+// Mapping: a persistent grid (resident workgroups only) walks the (plane, item) list with a grid
+// stride; one item = up to BLOCK_ROWS x BLOCK_COLS of one span, described by one 32-byte record;
 // each of the 4 waves takes whole rows, 64 lanes x 16 B per step, so every wave-instruction
 // stores one contiguous 1 KiB run of a canvas row.  Stores are 16-byte aligned on the canvas
 // side (the canvas pitch is arbitrary, so the alignment phase is recomputed per row); the tile
 // side is read with 16-byte loads at whatever 2-byte phase the placement leaves.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
 
 #include "common.h"
 
@@ -124,82 +129,143 @@ struct Pix<uint8_t> {
 // ---------------------------------------------------------------------------------------------
 // overwrite mode (the reference's semantics)
 // ---------------------------------------------------------------------------------------------
+// One wave moves ROWS_PER_WAVE rows of an item at a time.  All 16-byte loads of those rows are
+// issued before the first store, so each lane keeps up to ROWS_PER_WAVE * SLOTS loads in flight.
+constexpr int ROWS_PER_WAVE = BLOCK_ROWS / 4;
+
 template <typename T, int FLAT>
-__global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P) {
+struct RowJob {
+    static constexpr int VEC = Pix<T>::N;
+    static constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;   // vectors per lane per row (+1: alignment phase)
+    T *drow;
+    const T *srow;
+    const char *frow;
+    int mis, n, nvec;
+    u32x4 px[SLOTS];
+};
+
+template <typename T, int FLAT>
+__device__ __forceinline__ void row_load(RowJob<T, FLAT> &J, int lane) {
+    constexpr int VEC = RowJob<T, FLAT>::VEC;
+#pragma unroll
+    for (int k = 0; k < RowJob<T, FLAT>::SLOTS; ++k) {
+        const int p0 = (lane + 64 * k) * VEC - J.mis;
+        if (p0 >= 0 && p0 + VEC <= J.n) J.px[k] = ldg_nt<U32x4U>(J.srow + p0);
+    }
+}
+
+template <typename T, int FLAT>
+__device__ __forceinline__ void row_store(RowJob<T, FLAT> &J, int lane) {
+    constexpr int VEC = RowJob<T, FLAT>::VEC;
+#pragma unroll
+    for (int k = 0; k < RowJob<T, FLAT>::SLOTS; ++k) {
+        const int v = lane + 64 * k;
+        const int p0 = v * VEC - J.mis;
+        if (p0 >= 0 && p0 + VEC <= J.n) {
+            u32x4 px = J.px[k];
+            if (FLAT == 1 && J.frow) {
+                const float *f = reinterpret_cast<const float *>(J.frow) + p0;
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const f32x4 g = ldg<F32x4U>(f + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), g[e]));
+                }
+            } else if (FLAT == 2 && J.frow) {
+                const double *f = reinterpret_cast<const double *>(J.frow) + p0;
+#pragma unroll
+                for (int q = 0; q < VEC / 2; ++q) {
+                    const f64x2 g = ldg<F64x2U>(f + 2 * q);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), g[e]));
+                }
+            }
+            stg_nt(J.drow + p0, px);
+        } else if (v < J.nvec) {   // the (at most two) partial vectors at the ends of the row
+            for (int e = 0; e < VEC; ++e) {
+                const int p = p0 + e;
+                if (p >= 0 && p < J.n) {
+                    const T t = ldg_s<T>(J.srow + p);
+                    stg_s<T>(J.drow + p, J.frow ? correct_one<T, FLAT>(t, J.frow, p) : t);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
     constexpr int VEC = Pix<T>::N;
-    const Item it = P.items[blockIdx.x];
-    const int plane = blockIdx.y;
-    const Span sp = P.spans[it.span];
+    const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) & (VEC - 1));
+    const int nvec = (n + mis + VEC - 1) / VEC;
+    for (int v = lane; v < nvec; v += 64) {
+        const int p0 = v * VEC - mis;
+        if (p0 >= 0 && p0 + VEC <= n) {
+            stg_nt(drow + p0, u32x4{0, 0, 0, 0});
+        } else {
+            for (int e = 0; e < VEC; ++e)
+                if (p0 + e >= 0 && p0 + e < n) stg_s<T>(drow + p0 + e, 0);
+        }
+    }
+}
+
+template <typename T, int FLAT>
+__global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
+                                                              const int64_t n_work) {
+    constexpr int VEC = Pix<T>::N;
+    constexpr int FSZ = FLAT == 2 ? 8 : 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int rows = min(BLOCK_ROWS, sp.h - it.row0);
-    const int n = min(BLOCK_COLS, sp.w - it.col0);
 
-    T *canvas = static_cast<T *>(P.canvas) + plane * P.canvas_plane_stride;
-    const T *tile = nullptr;
-    const char *flat = nullptr;
-    int sy = 0, sx = 0;
-    if (sp.nref) {
-        const Ref rf = P.refs[sp.ref0];
-        tile = tile_ptr<T>(P, plane, rf.tile);
-        sy = rf.src_y + it.row0;
-        sx = rf.src_x + it.col0;
-        if (FLAT && P.flat_ptrs) flat = static_cast<const char *>(P.flat_ptrs[plane]);
-    }
-    constexpr int FSZ = FLAT == 2 ? 8 : 4;
+    // persistent grid-stride loop over (plane, item); the next descriptor and tile pointer are
+    // fetched while the current item streams
+    int64_t work = blockIdx.x;
+    if (work >= n_work) return;
+    int plane = (int)(work / n_items);
+    Item it = P.items[work - plane * n_items];
+    const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+    while (true) {
+        const int64_t nwork = work + gridDim.x;
+        const bool more = nwork < n_work;
+        int nplane = plane;
+        Item nit = it;
+        const T *ntile = nullptr;
+        if (more) {
+            nplane = (int)(nwork / n_items);
+            nit = P.items[nwork - nplane * n_items];
+            ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
+        }
 
-    for (int r = wave; r < rows; r += 4) {
-        T *drow = canvas + (int64_t)(sp.dst_y + it.row0 + r) * P.canvas_pitch + (sp.dst_x + it.col0);
-        const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) & (VEC - 1));
-        const int nvec = (n + mis + VEC - 1) / VEC;
-        if (!tile) {  // uncovered canvas: zeros (da.zeros, stitcher.py:362)
-            for (int v = lane; v < nvec; v += 64) {
-                const int p0 = v * VEC - mis;
-                if (p0 >= 0 && p0 + VEC <= n) {
-                    stg_nt(drow + p0, u32x4{0, 0, 0, 0});
-                } else {
-                    for (int e = 0; e < VEC; ++e)
-                        if (p0 + e >= 0 && p0 + e < n) stg_s<T>(drow + p0 + e, 0);
-                }
+        const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+        T *canvas = static_cast<T *>(P.canvas) + plane * P.canvas_plane_stride;
+        if (!it.nref) {   // uncovered canvas: zeros (da.zeros, stitcher.py:362)
+            for (int r = wave; r < rows; r += 4)
+                row_zero<T>(canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
+        } else {
+            const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+            RowJob<T, FLAT> J[ROWS_PER_WAVE];
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_WAVE; ++j) {
+                const int r = wave + 4 * j;
+                J[j].n = r < rows ? n : 0;
+                J[j].drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+                J[j].srow = tile + (int64_t)(it.b + r) * P.tile_pitch + it.c;
+                J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
+                J[j].mis = (int)((reinterpret_cast<uintptr_t>(J[j].drow) / sizeof(T)) & (VEC - 1));
+                J[j].nvec = J[j].n ? (J[j].n + J[j].mis + VEC - 1) / VEC : 0;
             }
-            continue;
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_WAVE; ++j) row_load<T, FLAT>(J[j], lane);
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_WAVE; ++j) row_store<T, FLAT>(J[j], lane);
         }
-        const T *srow = tile + (int64_t)(sy + r) * P.tile_pitch + sx;
-        const char *frow = (FLAT && flat) ? flat + ((int64_t)(sy + r) * P.tile_w + sx) * FSZ : nullptr;
-        for (int v = lane; v < nvec; v += 64) {
-            const int p0 = v * VEC - mis;
-            if (p0 >= 0 && p0 + VEC <= n) {
-                u32x4 px = ldg_nt<U32x4U>(srow + p0);
-                if (FLAT == 1 && frow) {
-                    const float *f = reinterpret_cast<const float *>(frow) + p0;
-#pragma unroll
-                    for (int q = 0; q < VEC / 4; ++q) {
-                        const f32x4 g = ldg<F32x4U>(f + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), g[e]));
-                    }
-                } else if (FLAT == 2 && frow) {
-                    const double *f = reinterpret_cast<const double *>(frow) + p0;
-#pragma unroll
-                    for (int q = 0; q < VEC / 2; ++q) {
-                        const f64x2 g = ldg<F64x2U>(f + 2 * q);
-#pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), g[e]));
-                    }
-                }
-                stg_nt(drow + p0, px);
-            } else {
-                for (int e = 0; e < VEC; ++e) {
-                    const int p = p0 + e;
-                    if (p >= 0 && p < n) {
-                        const T t = ldg_s<T>(srow + p);
-                        stg_s<T>(drow + p, frow ? correct_one<T, FLAT>(t, frow, p) : t);
-                    }
-                }
-            }
-        }
+        if (!more) break;
+        work = nwork;
+        plane = nplane;
+        it = nit;
+        tile = ntile;
     }
 }
 
@@ -211,55 +277,70 @@ __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P)
 // Compiled with -ffp-contract=off: multiply and add stay separate like numpy's.
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename OutT, int FLAT>
-__global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P) {
-    const Item it = P.items[blockIdx.x];
-    const int plane = blockIdx.y;
-    const Span sp = P.spans[it.span];
+__global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
+                                                            const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int rows = min(BLOCK_ROWS, sp.h - it.row0);
-    const int n = min(BLOCK_COLS, sp.w - it.col0);
-    OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
-    const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
     constexpr int FSZ = FLAT == 2 ? 8 : 4;
-    const int nref = sp.nref;
-
-    for (int r = wave; r < rows; r += 4) {
-        OutT *drow = canvas + (int64_t)(sp.dst_y + it.row0 + r) * P.canvas_pitch + (sp.dst_x + it.col0);
-        for (int p = lane; p < n; p += 64) {
-            float acc = 0.0f, wsum = 0.0f;
-            for (int k = 0; k < nref; ++k) {
-                const Ref rf = P.refs[sp.ref0 + k];
-                const T *tile = tile_ptr<T>(P, plane, rf.tile);
-                const int y = rf.src_y + it.row0 + r;
-                const int x = rf.src_x + it.col0 + p;
-                float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
-                if (FLAT && flat) {
-                    const char *g = flat + ((int64_t)y * P.tile_w + x) * FSZ;
-                    const float gf = FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g);
-                    v = __fdiv_rn(v, gf);
+    for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int plane = (int)(work / n_items);
+        const Item it = P.items[work - plane * n_items];
+        const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+        OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
+        const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+        const int nref = it.nref;
+        for (int r = wave; r < rows; r += 4) {
+            OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+            for (int p = lane; p < n; p += 64) {
+                float acc = 0.0f, wsum = 0.0f;
+                for (int k = 0; k < nref; ++k) {
+                    const Ref rf = P.refs[it.a + k];
+                    const T *tile = tile_ptr<T>(P, plane, rf.tile);
+                    const int y = rf.src_y + it.b + r;
+                    const int x = rf.src_x + it.c + p;
+                    float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
+                    if (FLAT && flat) {
+                        const char *g = flat + ((int64_t)y * P.tile_w + x) * FSZ;
+                        const float gf = FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g);
+                        v = __fdiv_rn(v, gf);
+                    }
+                    const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
+                    acc = __fadd_rn(acc, __fmul_rn(w, v));
+                    wsum = __fadd_rn(wsum, w);
                 }
-                const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
-                acc = __fadd_rn(acc, __fmul_rn(w, v));
-                wsum = __fadd_rn(wsum, w);
-            }
-            float o = wsum > 0.0f ? __fdiv_rn(acc, wsum) : 0.0f;
-            if (sizeof(OutT) == 4) {
-                stg_s<float>(reinterpret_cast<float *>(drow) + p, o);
-            } else {
-                const float hi = sizeof(OutT) == 1 ? 255.0f : 65535.0f;
-                o = fminf(fmaxf(rintf(o), 0.0f), hi);
-                stg_s<OutT>(drow + p, (OutT)o);
+                float o = wsum > 0.0f ? __fdiv_rn(acc, wsum) : 0.0f;
+                if (sizeof(OutT) == 4) {
+                    stg_s<float>(reinterpret_cast<float *>(drow) + p, o);
+                } else {
+                    const float hi = sizeof(OutT) == 1 ? 255.0f : 65535.0f;
+                    o = fminf(fmaxf(rintf(o), 0.0f), hi);
+                    stg_s<OutT>(drow + p, (OutT)o);
+                }
             }
         }
     }
 }
 
+// Persistent launch: as many workgroups as the chip keeps resident (queried once per kernel),
+// each walking the (plane, item) list with a grid stride.
 template <typename K>
 int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream) {
-    if (n_items == 0 || n_planes == 0) return SQ_OK;
-    dim3 grid((unsigned)n_items, (unsigned)n_planes, 1);
-    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, P);
+    const int64_t n_work = n_items * n_planes;
+    if (n_work == 0) return SQ_OK;
+    static thread_local std::map<const void *, int> resident;
+    const void *key = reinterpret_cast<const void *>(kernel);
+    auto it = resident.find(key);
+    if (it == resident.end()) {
+        int dev = 0, cus = 256, per_cu = 8;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        it = resident.emplace(key, cus * std::min(per_cu, 8)).first;
+    }
+    const int grid_override = getenv("SQ_FUSE_GRID") ? atoi(getenv("SQ_FUSE_GRID")) : 0;
+    const int64_t blocks = std::min<int64_t>(n_work, grid_override > 0 ? grid_override : it->second);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, stream, P, n_items, n_work);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_planes: launch failed: %s", hipGetErrorString(e));
     return SQ_OK;
@@ -284,7 +365,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: no tile table and no tile base");
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
-    if (a->n_planes < 0 || a->n_planes > 65535) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
+    if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
         return fail(SQ_ERR_UNSUPPORTED, "sq_fuse_planes: tile dtype %d (uint8/uint16 only)", a->tile_dtype);
     if (a->flat_ptrs_dev && a->flat_dtype != SQ_F32 && a->flat_dtype != SQ_F64)

@@ -181,9 +181,33 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     }
 
     std::vector<Item> items;
-    for (size_t s = 0; s < spans.size(); ++s)
-        for (int r0 = 0; r0 < spans[s].h; r0 += BLOCK_ROWS)
-            for (int c0 = 0; c0 < spans[s].w; c0 += BLOCK_COLS) items.push_back({(int32_t)s, r0, c0, 0});
+    for (size_t s = 0; s < spans.size(); ++s) {
+        const Span &sp = spans[s];
+        for (int r0 = 0; r0 < sp.h; r0 += BLOCK_ROWS)
+            for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
+                Item it{};
+                it.dst_y = sp.dst_y + r0;
+                it.dst_x = sp.dst_x + c0;
+                it.hw = (std::min(BLOCK_ROWS, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
+                it.nref = sp.nref;
+                it.span = (int32_t)s;
+                if (mode == SQ_FUSE_OVERWRITE) {
+                    if (sp.nref) {
+                        const Ref &rf = refs[sp.ref0];
+                        it.a = rf.tile;
+                        it.b = rf.src_y + r0;
+                        it.c = rf.src_x + c0;
+                    } else {
+                        it.a = -1;
+                    }
+                } else {
+                    it.a = sp.ref0;
+                    it.b = r0;
+                    it.c = c0;
+                }
+                items.push_back(it);
+            }
+    }
 
     auto *plan = new sq_fuse_plan;
     TableHeader hd{};

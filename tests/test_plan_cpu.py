@@ -19,7 +19,8 @@ HDR = np.dtype([('magic', '<u4'), ('mode', '<i4'), ('canvas_h', '<i4'), ('canvas
 SPAN = np.dtype([('dst_y', '<i4'), ('dst_x', '<i4'), ('h', '<i4'), ('w', '<i4'), ('nref', '<i4'), ('ref0', '<i4'),
                  ('pad', '<i4', (2,))])
 REF = np.dtype([('tile', '<i4'), ('src_y', '<i4'), ('src_x', '<i4'), ('pad', '<i4')])
-ITEM = np.dtype([('span', '<i4'), ('row0', '<i4'), ('col0', '<i4'), ('pad', '<i4')])
+ITEM = np.dtype([('dst_y', '<i4'), ('dst_x', '<i4'), ('hw', '<i4'), ('nref', '<i4'), ('a', '<i4'), ('b', '<i4'),
+                 ('c', '<i4'), ('span', '<i4')])
 
 
 def decode(plan):
@@ -37,17 +38,17 @@ def replay_overwrite(plan, tiles, flat=None):
     out = np.full((plan.canvas_h, plan.canvas_w), 0xAAAA, dtype=tiles.dtype)   # poison: every voxel must be written
     hits = np.zeros((plan.canvas_h, plan.canvas_w), dtype=np.int32)
     for it in items:
+        h, w = it['hw'] >> 16, it['hw'] & 0xFFFF
+        assert 0 < h <= 8 and 0 < w <= 2048
+        ys, xs = it['dst_y'], it['dst_x']
         sp = spans[it['span']]
-        r0, c0 = it['row0'], it['col0']
-        h, w = min(8, sp['h'] - r0), min(2048, sp['w'] - c0)
-        ys, xs = sp['dst_y'] + r0, sp['dst_x'] + c0
+        assert sp['dst_y'] <= ys and ys + h <= sp['dst_y'] + sp['h'] and sp['dst_x'] <= xs and xs + w <= sp['dst_x'] + sp['w']
         hits[ys:ys + h, xs:xs + w] += 1
-        if sp['nref'] == 0:
+        if it['nref'] == 0:
             out[ys:ys + h, xs:xs + w] = 0
             continue
-        rf = refs[sp['ref0']]
-        sy, sx = rf['src_y'] + r0, rf['src_x'] + c0
-        src = tiles[rf['tile'], sy:sy + h, sx:sx + w]
+        sy, sx = it['b'], it['c']
+        src = tiles[it['a'], sy:sy + h, sx:sx + w]
         if flat is not None:
             src = O.apply_flatfield(src, flat[sy:sy + h, sx:sx + w], tiles.dtype.type)
         out[ys:ys + h, xs:xs + w] = src

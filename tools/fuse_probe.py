@@ -19,10 +19,11 @@ def main():
     ap.add_argument('--ov', type=int, default=244)
     ap.add_argument('--flat', choices=['none', 'f32', 'f64'], default='none')
     ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--drift', type=int, nargs=2, default=[3, -2])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g, T = a.grid, a.tile
-    shifts = placement.Shifts((3, -a.ov), (-a.ov, -2))
+    shifts = placement.Shifts((a.drift[0], -a.ov), (-a.ov, a.drift[1]))
     rects = placement.grid_rects(g, g, T, T, shifts)
     wc, hc = placement.canvas_size(g, g, T, T, use_registration=True, shifts=shifts)
     t0 = time.time()
