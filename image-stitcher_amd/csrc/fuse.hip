@@ -56,6 +56,7 @@ __device__ __forceinline__ S ldg_s(const void *p) {
     return *(const SQ_GLOBAL S *)p;
 }
 __device__ __forceinline__ void stg_nt(void *p, u32x4 v) { __builtin_nontemporal_store(v, (SQ_GLOBAL u32x4 *)p); }
+__device__ __forceinline__ void stg(void *p, u32x4 v) { *(SQ_GLOBAL u32x4 *)p = v; }
 template <typename S>
 __device__ __forceinline__ void stg_s(void *p, S v) {
     *(SQ_GLOBAL S *)p = v;
@@ -86,7 +87,11 @@ __device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int
 // what the x86 cast of the reference produces; +inf -> dtype max through the clip.
 template <typename T>
 __device__ __forceinline__ T flat_f32(T v, float g) {
+#ifdef SQ_EXPERIMENT_FAKE_DIV
+    float q = (float)v * g;   // timing experiment only: wrong results
+#else
     float q = __fdiv_rn((float)v, g);
+#endif
     const float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
     q = fminf(fmaxf(q, 0.0f), hi);
     return (T)q;
@@ -129,93 +134,144 @@ struct Pix<uint8_t> {
 // ---------------------------------------------------------------------------------------------
 // overwrite mode (the reference's semantics)
 // ---------------------------------------------------------------------------------------------
-// One wave moves ROWS_PER_WAVE rows of an item at a time.  All 16-byte loads of those rows are
-// issued before the first store, so each lane keeps up to ROWS_PER_WAVE * SLOTS loads in flight.
-constexpr int ROWS_PER_WAVE = BLOCK_ROWS / 4;
-
-template <typename T, int FLAT>
-struct RowJob {
-    static constexpr int VEC = Pix<T>::N;
-    static constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;   // vectors per lane per row (+1: alignment phase)
+// One wave moves RB = BLOCK_ROWS/4 rows of an item as a software pipeline over (row, slot) steps,
+// a slot being one 16-byte vector per lane (64 lanes = 1 KiB of a canvas row).  Step s issues the
+// loads of slot s (pixels, flatfield gains, and -- with the row's first slot -- the row's edge
+// pixels) and then finishes slot s - DEPTH (divide, clip, pack, store).  vmcnt is in issue order,
+// so a finishing slot waits only for loads at least as old as its own: younger loads and stores
+// stay in flight.  DEPTH = all steps for the plain copy (every load of the item is in flight
+// before the first store); 1-2 with a flatfield, where registers buy occupancy that hides the
+// divide behind other waves' memory time.
+// A row's edges (canvas pixels before the first / after the last whole 16-byte vector) are done
+// one pixel per lane by lanes 0..2*VEC-1: one 2-byte load and one 2-byte store per wave and row.
+template <typename T>
+struct Row {
     T *drow;
     const T *srow;
     const char *frow;
-    int mis, n, nvec;
-    u32x4 px[SLOTS];
+    int mis, n;
+    int v_first, v_end;   // whole vectors are v in [v_first, v_end)
+    int edge_p;           // this lane's edge pixel (or -1)
 };
 
 template <typename T, int FLAT>
-__device__ __forceinline__ void row_load(RowJob<T, FLAT> &J, int lane) {
-    constexpr int VEC = RowJob<T, FLAT>::VEC;
+struct Slot {
+    static constexpr int VEC = Pix<T>::N;
+    u32x4 px;
+    f32x4 g32[FLAT == 1 ? VEC / 4 : 1];
+    f64x2 g64[FLAT == 2 ? VEC / 2 : 1];
+    T edge;
+    float eg32;
+    double eg64;
+};
+
+template <typename T>
+__device__ __forceinline__ void row_setup(Row<T> &J, int lane) {
+    constexpr int VEC = Pix<T>::N;
+    J.mis = (int)((reinterpret_cast<uintptr_t>(J.drow) / sizeof(T)) & (VEC - 1));
+    J.v_first = J.mis ? 1 : 0;
+    J.v_end = (J.n + J.mis) / VEC;
+    const int head_end = min(J.n, J.v_first * VEC - J.mis);        // pixels [0, head_end)
+    const int tail_start = max(head_end, J.v_end * VEC - J.mis);   // pixels [tail_start, n)
+    int p = -1;
+    if (lane < VEC) {
+        if (lane < head_end) p = lane;
+    } else if (lane < 2 * VEC) {
+        if (tail_start + (lane - VEC) < J.n) p = tail_start + (lane - VEC);
+    }
+    J.edge_p = p;
+}
+
+// plain loads: the tile is read once, but non-temporal loads measured 3-8 % slower here
+template <typename T, int FLAT>
+__device__ __forceinline__ void slot_load(Slot<T, FLAT> &S, const Row<T> &J, int lane, int k) {
+    constexpr int VEC = Pix<T>::N;
+    const int v = lane + 64 * k;
+    if (v >= J.v_first && v < J.v_end) {
+        const int p0 = v * VEC - J.mis;
+        S.px = ldg<U32x4U>(J.srow + p0);
+        if (FLAT == 1 && J.frow) {
 #pragma unroll
-    for (int k = 0; k < RowJob<T, FLAT>::SLOTS; ++k) {
-        const int p0 = (lane + 64 * k) * VEC - J.mis;
-        if (p0 >= 0 && p0 + VEC <= J.n) J.px[k] = ldg_nt<U32x4U>(J.srow + p0);
+            for (int q = 0; q < VEC / 4; ++q) S.g32[q] = ldg<F32x4U>(reinterpret_cast<const float *>(J.frow) + p0 + 4 * q);
+        }
+        if (FLAT == 2 && J.frow) {
+#pragma unroll
+            for (int q = 0; q < VEC / 2; ++q) S.g64[q] = ldg<F64x2U>(reinterpret_cast<const double *>(J.frow) + p0 + 2 * q);
+        }
+    }
+    if (k == 0 && J.edge_p >= 0) {
+        S.edge = ldg_s<T>(J.srow + J.edge_p);
+        if (FLAT == 1 && J.frow) S.eg32 = ldg_s<float>(reinterpret_cast<const float *>(J.frow) + J.edge_p);
+        if (FLAT == 2 && J.frow) S.eg64 = ldg_s<double>(reinterpret_cast<const double *>(J.frow) + J.edge_p);
     }
 }
 
+// non-temporal stores: the canvas is written once and never read back by this kernel
 template <typename T, int FLAT>
-__device__ __forceinline__ void row_store(RowJob<T, FLAT> &J, int lane) {
-    constexpr int VEC = RowJob<T, FLAT>::VEC;
+__device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, int lane, int k) {
+    constexpr int VEC = Pix<T>::N;
+    const int v = lane + 64 * k;
+    if (v >= J.v_first && v < J.v_end) {
+        u32x4 px = S.px;
+        if (FLAT == 1 && J.frow) {
 #pragma unroll
-    for (int k = 0; k < RowJob<T, FLAT>::SLOTS; ++k) {
-        const int v = lane + 64 * k;
-        const int p0 = v * VEC - J.mis;
-        if (p0 >= 0 && p0 + VEC <= J.n) {
-            u32x4 px = J.px[k];
-            if (FLAT == 1 && J.frow) {
-                const float *f = reinterpret_cast<const float *>(J.frow) + p0;
+            for (int q = 0; q < VEC / 4; ++q)
 #pragma unroll
-                for (int q = 0; q < VEC / 4; ++q) {
-                    const f32x4 g = ldg<F32x4U>(f + 4 * q);
+                for (int e = 0; e < 4; ++e)
+                    Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+        } else if (FLAT == 2 && J.frow) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), g[e]));
-                }
-            } else if (FLAT == 2 && J.frow) {
-                const double *f = reinterpret_cast<const double *>(J.frow) + p0;
+            for (int q = 0; q < VEC / 2; ++q)
 #pragma unroll
-                for (int q = 0; q < VEC / 2; ++q) {
-                    const f64x2 g = ldg<F64x2U>(f + 2 * q);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), g[e]));
-                }
-            }
-            stg_nt(J.drow + p0, px);
-        } else if (v < J.nvec) {   // the (at most two) partial vectors at the ends of the row
-            for (int e = 0; e < VEC; ++e) {
-                const int p = p0 + e;
-                if (p >= 0 && p < J.n) {
-                    const T t = ldg_s<T>(J.srow + p);
-                    stg_s<T>(J.drow + p, J.frow ? correct_one<T, FLAT>(t, J.frow, p) : t);
-                }
-            }
+                for (int e = 0; e < 2; ++e)
+                    Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), S.g64[q][e]));
         }
+        stg_nt(J.drow + (v * VEC - J.mis), px);
+    }
+    if (k == 0 && J.edge_p >= 0) {
+        T t = S.edge;
+        if (FLAT == 1 && J.frow) t = flat_f32<T>(t, S.eg32);
+        if (FLAT == 2 && J.frow) t = flat_f64<T>(t, S.eg64);
+        stg_s<T>(J.drow + J.edge_p, t);
     }
 }
 
 template <typename T>
 __device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
     constexpr int VEC = Pix<T>::N;
-    const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(T)) & (VEC - 1));
-    const int nvec = (n + mis + VEC - 1) / VEC;
-    for (int v = lane; v < nvec; v += 64) {
-        const int p0 = v * VEC - mis;
-        if (p0 >= 0 && p0 + VEC <= n) {
-            stg_nt(drow + p0, u32x4{0, 0, 0, 0});
-        } else {
-            for (int e = 0; e < VEC; ++e)
-                if (p0 + e >= 0 && p0 + e < n) stg_s<T>(drow + p0 + e, 0);
-        }
+    constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
+    Row<T> J;
+    J.drow = drow;
+    J.n = n;
+    row_setup<T>(J, lane);
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int v = lane + 64 * k;
+        if (v >= J.v_first && v < J.v_end) stg_nt(drow + (v * VEC - J.mis), u32x4{0, 0, 0, 0});
     }
+    if (J.edge_p >= 0) stg_s<T>(drow + J.edge_p, 0);
 }
+
+#ifndef SQ_DEPTH_PLAIN
+#define SQ_DEPTH_PLAIN 16
+#endif
+#ifndef SQ_DEPTH_F32
+#define SQ_DEPTH_F32 2
+#endif
+#ifndef SQ_DEPTH_F64
+#define SQ_DEPTH_F64 1
+#endif
 
 template <typename T, int FLAT>
 __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
                                                               const int64_t n_work) {
     constexpr int VEC = Pix<T>::N;
     constexpr int FSZ = FLAT == 2 ? 8 : 4;
+    constexpr int RB = BLOCK_ROWS / 4;
+    constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;   // vectors per lane per row (+1: alignment phase)
+    constexpr int NSTEP = RB * SLOTS;
+    constexpr int WANT = FLAT == 0 ? SQ_DEPTH_PLAIN : (FLAT == 1 ? SQ_DEPTH_F32 : SQ_DEPTH_F64);
+    constexpr int DEPTH = WANT < NSTEP ? WANT : NSTEP;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -245,21 +301,25 @@ __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P,
                 row_zero<T>(canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
         } else {
             const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
-            RowJob<T, FLAT> J[ROWS_PER_WAVE];
+            Row<T> J[RB];
 #pragma unroll
-            for (int j = 0; j < ROWS_PER_WAVE; ++j) {
+            for (int j = 0; j < RB; ++j) {
                 const int r = wave + 4 * j;
                 J[j].n = r < rows ? n : 0;
                 J[j].drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
                 J[j].srow = tile + (int64_t)(it.b + r) * P.tile_pitch + it.c;
                 J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
-                J[j].mis = (int)((reinterpret_cast<uintptr_t>(J[j].drow) / sizeof(T)) & (VEC - 1));
-                J[j].nvec = J[j].n ? (J[j].n + J[j].mis + VEC - 1) / VEC : 0;
+                row_setup<T>(J[j], lane);
             }
+            Slot<T, FLAT> buf[DEPTH + 1];
 #pragma unroll
-            for (int j = 0; j < ROWS_PER_WAVE; ++j) row_load<T, FLAT>(J[j], lane);
-#pragma unroll
-            for (int j = 0; j < ROWS_PER_WAVE; ++j) row_store<T, FLAT>(J[j], lane);
+            for (int s = 0; s < NSTEP + DEPTH; ++s) {
+                if (s < NSTEP) slot_load<T, FLAT>(buf[s % (DEPTH + 1)], J[s / SLOTS], lane, s % SLOTS);
+                if (s >= DEPTH) {
+                    const int d = s - DEPTH;
+                    slot_store<T, FLAT>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
+                }
+            }
         }
         if (!more) break;
         work = nwork;

@@ -7,6 +7,7 @@
 // feather: all rects that cover it, in write order), merge equal neighbours horizontally and
 // then vertically.  The device then writes every canvas voxel exactly once.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -207,6 +208,24 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 }
                 items.push_back(it);
             }
+    }
+
+    // Overwrite mode: walk the tiles "row-synchronously".  Items are ordered by the tile row they
+    // read, then by tile, so the workgroups resident at any moment read the same few rows of
+    // different tiles -- and therefore the same few rows of the flatfield, which then stays in
+    // the XCDs' L2 instead of being re-fetched from the Infinity Cache for every tile.  Every item
+    // still moves whole row segments, so HBM sees the same contiguous runs in a different order.
+    const char *order_env = getenv("SQ_PLAN_ORDER");
+    const bool row_sync = order_env ? atoi(order_env) != 0 : true;
+    if (mode == SQ_FUSE_OVERWRITE && row_sync) {
+        std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) {
+            const bool zx = x.nref == 0, zy = y.nref == 0;
+            if (zx != zy) return zy;                       // covered items first, zero-fill last
+            if (zx) return false;
+            const int bx = x.b / BLOCK_ROWS, by = y.b / BLOCK_ROWS;
+            if (bx != by) return bx < by;
+            return false;                                  // stable: keeps tile / span order inside a row block
+        });
     }
 
     auto *plan = new sq_fuse_plan;

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsquidstitch.so')
+LIB_PATH = os.environ.get('SQ_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsquidstitch.so')
 
 SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
