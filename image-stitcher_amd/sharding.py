@@ -57,7 +57,7 @@ def all_gather_shift_table(local_rows: np.ndarray, device=None, group=None) -> n
     t = torch.from_numpy(local_rows)
     if device is not None:
         t = t.to(device)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    out = torch.empty((world * t.shape[0], SHIFT_ROW), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     return out.cpu().numpy().reshape(-1, SHIFT_ROW)
 
