@@ -210,14 +210,18 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             }
     }
 
-    // Overwrite mode: walk the tiles "row-synchronously".  Items are ordered by the tile row they
-    // read, then by tile, so the workgroups resident at any moment read the same few rows of
-    // different tiles -- and therefore the same few rows of the flatfield, which then stays in
-    // the XCDs' L2 instead of being re-fetched from the Infinity Cache for every tile.  Every item
-    // still moves whole row segments, so HBM sees the same contiguous runs in a different order.
+    // Overwrite mode: walk the tiles "row-synchronously", one tile-row block per XCD.
+    // Items are grouped by the block of BLOCK_ROWS tile rows they read (all tiles, in tile order).
+    // Workgroup b of the persistent grid takes items b, b + G, ... and workgroups are dealt to the
+    // 8 XCDs round-robin, so list position i is served by XCD i % 8 (observed placement: a speed
+    // matter only).  Row block r is therefore laid out on positions == r (mod 8): the ~128
+    // workgroups resident on one XCD all read the same 8 rows of the flatfield at the same time,
+    // which are fetched into that XCD's L2 once instead of once per tile.  Every item still moves
+    // whole row segments, so HBM sees the same contiguous runs, in a different order.
+    //   SQ_PLAN_ORDER=0 keeps span order, 1 = row blocks without the XCD interleave (experiments).
     const char *order_env = getenv("SQ_PLAN_ORDER");
-    const bool row_sync = order_env ? atoi(order_env) != 0 : true;
-    if (mode == SQ_FUSE_OVERWRITE && row_sync) {
+    const int order_mode = order_env ? atoi(order_env) : 2;
+    if (mode == SQ_FUSE_OVERWRITE && order_mode > 0) {
         std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) {
             const bool zx = x.nref == 0, zy = y.nref == 0;
             if (zx != zy) return zy;                       // covered items first, zero-fill last
@@ -226,6 +230,23 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             if (bx != by) return bx < by;
             return false;                                  // stable: keeps tile / span order inside a row block
         });
+        if (order_mode > 1) {
+            constexpr int NX = 8;
+            std::vector<Item> lane[NX], rest;
+            for (const Item &it : items) {
+                if (it.nref) lane[(it.b / BLOCK_ROWS) % NX].push_back(it);
+                else rest.push_back(it);
+            }
+            std::vector<Item> out;
+            out.reserve(items.size());
+            size_t common = lane[0].size();
+            for (int x = 1; x < NX; ++x) common = std::min(common, lane[x].size());
+            for (size_t k = 0; k < common; ++k)
+                for (int x = 0; x < NX; ++x) out.push_back(lane[x][k]);
+            for (int x = 0; x < NX; ++x) out.insert(out.end(), lane[x].begin() + common, lane[x].end());
+            out.insert(out.end(), rest.begin(), rest.end());
+            items.swap(out);
+        }
     }
 
     auto *plan = new sq_fuse_plan;
