@@ -26,8 +26,14 @@ inline int fail(int code, const char *fmt, ...) {
 // whose every voxel is produced from the same ordered list of tiles ("refs"): none (zero
 // fill), one (overwrite mode: the last writer), or several (feather mode).
 constexpr uint32_t TABLE_MAGIC = 0x53514654u;  // "SQFT"
-constexpr int BLOCK_ROWS = 8;                  // rows of a span one workgroup takes
-constexpr int BLOCK_COLS = 2048;               // columns of a span one workgroup takes
+#ifndef SQ_BLOCK_ROWS
+#define SQ_BLOCK_ROWS 8
+#endif
+#ifndef SQ_BLOCK_COLS
+#define SQ_BLOCK_COLS 2048
+#endif
+constexpr int BLOCK_ROWS = SQ_BLOCK_ROWS;      // rows of a span one workgroup takes (multiple of 4: one wave per row)
+constexpr int BLOCK_COLS = SQ_BLOCK_COLS;      // columns of a span one workgroup takes
 constexpr int MAX_REFS = 8;                    // feather: most tiles blended in one span
 
 struct TableHeader {
