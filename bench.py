@@ -131,18 +131,30 @@ def main():
     fuse_events = []
     state = {}
 
+    lap = {}
+
+    def tick(name, t_prev):
+        t = time.perf_counter()
+        lap[name] = lap.get(name, 0.0) + (t - t_prev)
+        return t
+
     def step(record):
+        t = time.perf_counter()
         # registration: centre pairs on the registration plane (stitcher.py:422-498)
         shifts = registration.register_grid_center(reg_plane, g, g, xs, ys, spec.pixel_size_um,
                                                    spec.pixel_binning, normalization='phase')
+        t = tick('register', t)
         table = sharding.all_gather_shift_table(sharding.shifts_to_row(shifts)[None], device=dev)
         mine = sharding.row_to_shifts(table[rank])
+        t = tick('allgather', t)
         # host integer geometry + span plan (rebuilt every step: it depends on the shifts)
         rects = placement.grid_rects(g, g, TILE, TILE, mine, order=order_rc)
         w_px, h_px = placement.canvas_size(g, g, TILE, TILE, use_registration=True, shifts=mine)
         if (w_px, h_px) != (wc, hc):
             raise RuntimeError(f"registration returned {mine}, canvas {h_px}x{w_px} != planned {hc}x{wc}")
+        t = tick('rects', t)
         plan = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE)
+        t = tick('plan', t)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -151,6 +163,7 @@ def main():
             e1.record()
             fuse_events.append((e0, e1))
         state['plan'], state['shifts'] = plan, mine
+        tick('fuse_launch', t)
 
     def fence():
         torch.cuda.synchronize()
@@ -182,6 +195,17 @@ def main():
     # + the float32 flatfield once per plane
     alg_bytes = n_planes * (covered * 4 + (hc * wc - covered) * 2 + (TILE * TILE * 4 if wl['flat'] else 0))
     achieved = alg_bytes / (fuse_ms * 1e-3) / 1e9
+    traffic = args.traffic_bytes
+    if traffic is None:
+        # PMC counters need their own rocprofv3 passes; the last committed measurement of this exact
+        # launch (same workload, same plane count) is reported, else null
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')) as fh:
+                pm = json.load(fh)
+            if pm.get('workload') == args.workload and pm.get('planes') == n_planes:
+                traffic = pm['traffic_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            traffic = None
 
     out = {
         'metric': 'stitched Mvoxels/s', 'value': round(value, 1), 'unit': 'Mvoxel/s',
@@ -195,10 +219,13 @@ def main():
                    'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes'},
         'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_kernel<u16,f32 flat>' if wl['flat'] else 'fuse_overwrite_kernel<u16>',
                      'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': args.traffic_bytes,
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                      'algorithmic_bytes_per_launch': int(alg_bytes), 'launch_ms': round(fuse_ms, 4)},
     }
 
+    if rank == 0 and os.environ.get('SQ_BENCH_BREAKDOWN'):
+        n = args.steps + args.warmup
+        print('[bench] host ms per step: ' + ', '.join(f'{k} {v / n * 1e3:.2f}' for k, v in lap.items()), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth)
     if rank == 0:

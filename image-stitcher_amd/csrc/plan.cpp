@@ -7,9 +7,9 @@
 // feather: all rects that cover it, in write order), merge equal neighbours horizontally and
 // then vertically.  The device then writes every canvas voxel exactly once.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <vector>
 
 #include "common.h"
@@ -31,21 +31,6 @@ struct Clipped {
     int tile;
 };
 
-struct OpenSpan {
-    int64_t index;  // into spans
-    int y_end;
-};
-
-struct Key {
-    int xa, xb;
-    std::vector<int> owners;
-    bool operator<(const Key &o) const {
-        if (xa != o.xa) return xa < o.xa;
-        if (xb != o.xb) return xb < o.xb;
-        return owners < o.owners;
-    }
-};
-
 }  // namespace
 
 extern "C" {
@@ -64,6 +49,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         fail(SQ_ERR_INVALID, "sq_fuse_plan_create: unknown mode %d", mode);
         return nullptr;
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     // Canvas clip of stitcher.py:590-594 (python slice semantics) + validation of the source side.
     std::vector<Clipped> cl;
     cl.reserve(n_rects);
@@ -105,12 +91,24 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 
     std::vector<Span> spans;
     std::vector<Ref> refs;
-    std::map<Key, OpenSpan> open, open_next;
     int max_refs = 0;
     int64_t covered = 0;
 
+    // spans of the previous band that may continue into this one, sorted by xa (they are produced
+    // left to right); the current band's intervals are produced left to right too, so matching a
+    // continuation is a two-pointer walk
+    struct Open {
+        int xa, xb;
+        int64_t index;   // into spans
+        int owner0;      // first owner (clipped-rect index) or -1
+        int nown;
+    };
+    std::vector<Open> open, open_next;
+    std::vector<int> open_owners, open_owners_next;   // owner lists of `open`, concatenated (feather)
+    std::vector<int> open_off, open_off_next;
+
     std::vector<int> xs;
-    std::vector<int> owners;
+    std::vector<int> owners, cur_owners;
     for (size_t b = 0; b + 1 < ys.size(); ++b) {
         const int ya = ys[b], yb = ys[b + 1];
         while (next < by_y0.size() && cl[by_y0[next]].y0 <= ya) {
@@ -119,7 +117,9 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         }
         active.erase(std::remove_if(active.begin(), active.end(), [&](int i) { return cl[i].y1 <= ya; }), active.end());
 
-        xs.assign({0, canvas_w});
+        xs.clear();
+        xs.push_back(0);
+        xs.push_back(canvas_w);
         for (int i : active) {
             xs.push_back(cl[i].x0);
             xs.push_back(cl[i].x1);
@@ -128,126 +128,136 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
 
         open_next.clear();
-        Key cur;
+        open_owners_next.clear();
+        open_off_next.clear();
+        size_t op = 0;   // pointer into `open`
+        int cur_xa = 0, cur_xb = 0;
         bool have = false;
         auto flush = [&]() {
             if (!have) return;
-            auto it = open.find(cur);
-            if (it != open.end() && it->second.y_end == ya) {
-                Span &s = spans[it->second.index];
-                s.h += yb - ya;
-                open_next[cur] = {it->second.index, yb};
-            } else {
-                Span s{};
-                s.dst_y = ya;
-                s.dst_x = cur.xa;
-                s.h = yb - ya;
-                s.w = cur.xb - cur.xa;
-                s.nref = (int)cur.owners.size();
-                s.ref0 = (int)refs.size();
-                for (int o : cur.owners) {
-                    const Clipped &c = cl[o];
-                    refs.push_back({c.tile, c.src_y + (ya - c.y0), c.src_x + (cur.xa - c.x0), 0});
-                }
-                open_next[cur] = {(int64_t)spans.size(), yb};
-                spans.push_back(s);
+            while (op < open.size() && open[op].xa < cur_xa) ++op;
+            bool cont = false;
+            if (op < open.size() && open[op].xa == cur_xa && open[op].xb == cur_xb &&
+                open[op].nown == (int)cur_owners.size()) {
+                cont = true;
+                const int *po = open_owners.data() + open_off[op];
+                for (size_t k = 0; k < cur_owners.size(); ++k)
+                    if (po[k] != cur_owners[k]) {
+                        cont = false;
+                        break;
+                    }
             }
-            if (!cur.owners.empty()) covered += (int64_t)(yb - ya) * (cur.xb - cur.xa);
-            max_refs = std::max(max_refs, (int)cur.owners.size());
+            int64_t index;
+            if (cont) {
+                index = open[op].index;
+                spans[index].h += yb - ya;
+            } else {
+                Span sp{};
+                sp.dst_y = ya;
+                sp.dst_x = cur_xa;
+                sp.h = yb - ya;
+                sp.w = cur_xb - cur_xa;
+                sp.nref = (int)cur_owners.size();
+                sp.ref0 = (int)refs.size();
+                for (int o : cur_owners) {
+                    const Clipped &c = cl[o];
+                    refs.push_back({c.tile, c.src_y + (ya - c.y0), c.src_x + (cur_xa - c.x0), 0});
+                }
+                index = (int64_t)spans.size();
+                spans.push_back(sp);
+            }
+            open_off_next.push_back((int)open_owners_next.size());
+            open_owners_next.insert(open_owners_next.end(), cur_owners.begin(), cur_owners.end());
+            open_next.push_back({cur_xa, cur_xb, index, cur_owners.empty() ? -1 : cur_owners[0], (int)cur_owners.size()});
+            if (!cur_owners.empty()) covered += (int64_t)(yb - ya) * (cur_xb - cur_xa);
+            max_refs = std::max(max_refs, (int)cur_owners.size());
             have = false;
         };
         for (size_t k = 0; k + 1 < xs.size(); ++k) {
             const int xa = xs[k], xb = xs[k + 1];
             owners.clear();
-            for (int i : active)
-                if (cl[i].x0 <= xa && cl[i].x1 >= xb) owners.push_back(i);
-            if (mode == SQ_FUSE_OVERWRITE && owners.size() > 1) owners.erase(owners.begin(), owners.end() - 1);
+            if (mode == SQ_FUSE_OVERWRITE) {
+                for (size_t a = active.size(); a-- > 0;) {   // last writer wins: search from the back
+                    const Clipped &c = cl[active[a]];
+                    if (c.x0 <= xa && c.x1 >= xb) {
+                        owners.push_back(active[a]);
+                        break;
+                    }
+                }
+            } else {
+                for (int i : active)
+                    if (cl[i].x0 <= xa && cl[i].x1 >= xb) owners.push_back(i);
+            }
             if ((int)owners.size() > MAX_REFS) {
                 fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: %zu tiles overlap at canvas (%d,%d); feather supports %d",
                      owners.size(), ya, xa, MAX_REFS);
                 return nullptr;
             }
-            if (have && cur.owners == owners && cur.xb == xa) {
-                cur.xb = xb;
+            if (have && cur_owners == owners && cur_xb == xa) {
+                cur_xb = xb;
             } else {
                 flush();
-                cur.xa = xa;
-                cur.xb = xb;
-                cur.owners = owners;
+                cur_xa = xa;
+                cur_xb = xb;
+                cur_owners = owners;
                 have = true;
             }
         }
         flush();
         open.swap(open_next);
+        open_owners.swap(open_owners_next);
+        open_off.swap(open_off_next);
     }
 
-    std::vector<Item> items;
-    for (size_t s = 0; s < spans.size(); ++s) {
-        const Span &sp = spans[s];
-        for (int r0 = 0; r0 < sp.h; r0 += BLOCK_ROWS)
-            for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
-                Item it{};
-                it.dst_y = sp.dst_y + r0;
-                it.dst_x = sp.dst_x + c0;
-                it.hw = (std::min(BLOCK_ROWS, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
-                it.nref = sp.nref;
-                it.span = (int32_t)s;
-                if (mode == SQ_FUSE_OVERWRITE) {
-                    if (sp.nref) {
-                        const Ref &rf = refs[sp.ref0];
-                        it.a = rf.tile;
-                        it.b = rf.src_y + r0;
-                        it.c = rf.src_x + c0;
-                    } else {
-                        it.a = -1;
-                    }
-                } else {
-                    it.a = sp.ref0;
-                    it.b = r0;
-                    it.c = c0;
-                }
-                items.push_back(it);
-            }
-    }
+    const auto t_sweep = std::chrono::steady_clock::now();
 
-    // Overwrite mode: walk the tiles "row-synchronously", one tile-row block per XCD.
-    // Items are grouped by the block of BLOCK_ROWS tile rows they read (all tiles, in tile order).
-    // Workgroup b of the persistent grid takes items b, b + G, ... and workgroups are dealt to the
-    // 8 XCDs round-robin, so list position i is served by XCD i % 8 (observed placement: a speed
-    // matter only).  Row block r is therefore laid out on positions == r (mod 8): the ~128
-    // workgroups resident on one XCD all read the same 8 rows of the flatfield at the same time,
-    // which are fetched into that XCD's L2 once instead of once per tile.  Every item still moves
-    // whole row segments, so HBM sees the same contiguous runs, in a different order.
+    // ---- work items, generated straight into their final place in the table -----------------------
+    // Order (overwrite mode): "one tile-row block per XCD".  Items are grouped by the block of
+    // BLOCK_ROWS tile rows they read (all tiles, in tile order; a stable counting sort).  Workgroup b
+    // of the persistent grid takes items b, b + G, ... and workgroups are dealt to the 8 XCDs
+    // round-robin, so list position i is served by XCD i % 8 (observed placement: a speed matter
+    // only).  Row block r is therefore laid out on positions == r (mod 8): the ~128 workgroups
+    // resident on one XCD all read the same 8 rows of the flatfield at the same time, which are
+    // fetched into that XCD's L2 once instead of once per tile.  Every item still moves whole row
+    // segments, so HBM sees the same contiguous runs, in a different order.  Zero-fill items go last.
     //   SQ_PLAN_ORDER=0 keeps span order, 1 = row blocks without the XCD interleave (experiments).
     const char *order_env = getenv("SQ_PLAN_ORDER");
-    const int order_mode = order_env ? atoi(order_env) : 2;
-    if (mode == SQ_FUSE_OVERWRITE && order_mode > 0) {
-        std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) {
-            const bool zx = x.nref == 0, zy = y.nref == 0;
-            if (zx != zy) return zy;                       // covered items first, zero-fill last
-            if (zx) return false;
-            const int bx = x.b / BLOCK_ROWS, by = y.b / BLOCK_ROWS;
-            if (bx != by) return bx < by;
-            return false;                                  // stable: keeps tile / span order inside a row block
-        });
-        if (order_mode > 1) {
-            constexpr int NX = 8;
-            std::vector<Item> lane[NX], rest;
-            for (const Item &it : items) {
-                if (it.nref) lane[(it.b / BLOCK_ROWS) % NX].push_back(it);
-                else rest.push_back(it);
-            }
-            std::vector<Item> out;
-            out.reserve(items.size());
-            size_t common = lane[0].size();
-            for (int x = 1; x < NX; ++x) common = std::min(common, lane[x].size());
-            for (size_t k = 0; k < common; ++k)
-                for (int x = 0; x < NX; ++x) out.push_back(lane[x][k]);
-            for (int x = 0; x < NX; ++x) out.insert(out.end(), lane[x].begin() + common, lane[x].end());
-            out.insert(out.end(), rest.begin(), rest.end());
-            items.swap(out);
+    const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : 0;
+    constexpr int NX = 8;
+    const int nblk = tile_h / BLOCK_ROWS + 2;   // row blocks, +1 slack, +1 for the zero-fill bucket
+    auto for_each_item = [&](auto &&emit) {
+        for (size_t si = 0; si < spans.size(); ++si) {
+            const Span &sp = spans[si];
+            const Ref *rf = (mode == SQ_FUSE_OVERWRITE && sp.nref) ? &refs[sp.ref0] : nullptr;
+            for (int r0 = 0; r0 < sp.h; r0 += BLOCK_ROWS)
+                for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
+                    Item it;
+                    it.dst_y = sp.dst_y + r0;
+                    it.dst_x = sp.dst_x + c0;
+                    it.hw = (std::min(BLOCK_ROWS, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
+                    it.nref = sp.nref;
+                    it.span = (int32_t)si;
+                    if (mode == SQ_FUSE_OVERWRITE) {
+                        it.a = rf ? rf->tile : -1;
+                        it.b = rf ? rf->src_y + r0 : 0;
+                        it.c = rf ? rf->src_x + c0 : 0;
+                    } else {
+                        it.a = sp.ref0;
+                        it.b = r0;
+                        it.c = c0;
+                    }
+                    emit(it);
+                }
         }
-    }
+    };
+    auto key_of = [&](const Item &it) { return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1; };
+    std::vector<int64_t> count(nblk, 0);
+    int64_t n_items = 0;
+    for_each_item([&](const Item &it) {
+        ++count[order_mode ? key_of(it) : 0];
+        ++n_items;
+    });
+    const auto t_items = std::chrono::steady_clock::now();
 
     auto *plan = new sq_fuse_plan;
     TableHeader hd{};
@@ -261,7 +271,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     hd.max_refs = max_refs;
     hd.n_spans = (int64_t)spans.size();
     hd.n_refs = (int64_t)refs.size();
-    hd.n_items = (int64_t)items.size();
+    hd.n_items = n_items;
     hd.off_spans = sizeof(TableHeader);
     hd.off_refs = hd.off_spans + hd.n_spans * (int64_t)sizeof(Span);
     hd.off_items = hd.off_refs + hd.n_refs * (int64_t)sizeof(Ref);
@@ -272,7 +282,50 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     std::memcpy(p, &hd, sizeof hd);
     if (!spans.empty()) std::memcpy(p + hd.off_spans, spans.data(), spans.size() * sizeof(Span));
     if (!refs.empty()) std::memcpy(p + hd.off_refs, refs.data(), refs.size() * sizeof(Ref));
-    if (!items.empty()) std::memcpy(p + hd.off_items, items.data(), items.size() * sizeof(Item));
+    Item *dst = reinterpret_cast<Item *>(p + hd.off_items);
+    if (order_mode == 0) {
+        int64_t i = 0;
+        for_each_item([&](const Item &it) { dst[i++] = it; });
+    } else {
+        // position of the k-th item of bucket `key` in the row-block-sorted list ...
+        std::vector<int64_t> start(nblk + 1, 0);
+        for (int k = 0; k < nblk; ++k) start[k + 1] = start[k] + count[k];
+        // ... and, for the XCD interleave, its rank inside its lane (blocks of the lane in order)
+        std::vector<int64_t> lane_base(nblk, 0), lane_len(NX, 0);
+        for (int k = 0; k < nblk - 1; ++k) {
+            lane_base[k] = lane_len[k % NX];
+            lane_len[k % NX] += count[k];
+        }
+        int64_t common = lane_len[0];
+        for (int x = 1; x < NX; ++x) common = std::min(common, lane_len[x]);
+        std::vector<int64_t> tail_at(NX, 0);
+        int64_t tail = common * NX;   // the lanes' leftovers follow, lane by lane
+        for (int x = 0; x < NX; ++x) {
+            tail_at[x] = tail;
+            tail += lane_len[x] - common;
+        }
+        std::vector<int64_t> seen(nblk, 0);
+        for_each_item([&](const Item &it) {
+            const int k = key_of(it);
+            const int64_t j = seen[k]++;
+            int64_t pos;
+            if (k == nblk - 1 || order_mode == 1) {
+                pos = start[k] + j;
+            } else {
+                const int x = k % NX;
+                const int64_t t = lane_base[k] + j;
+                pos = t < common ? t * NX + x : tail_at[x] + (t - common);
+            }
+            dst[pos] = it;
+        });
+    }
+    const auto t_order = std::chrono::steady_clock::now();
+    const size_t n_spans_dbg = spans.size();
+    if (getenv("SQ_PLAN_TIMING")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[plan] sweep %.3f ms, count %.3f ms, emit %.3f ms (%zu spans, %lld items)\n",
+                ms(t_begin, t_sweep), ms(t_sweep, t_items), ms(t_items, t_order), n_spans_dbg, (long long)n_items);
+    }
     return plan;
 }
 

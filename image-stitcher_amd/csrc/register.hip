@@ -21,7 +21,8 @@
 //                  |.| and per-block argmax (first index wins ties, NaN wins like numpy)
 //   K4a peak       reduce block partials -> whole-pixel peak, wrap to signed shift (skimage :215-220)
 //   K4b upsample 1 D1[k0][b] = sum_k1 P[k0][k1] e^{+2 pi i (b-off1) f1[k1]}   (skimage :63-75, last axis)
-//   K4c upsample 2 cc_up[a][b] = sum_k0 D1[k0][b] e^{+2 pi i (a-off0) f0[k0]}, argmax |.| (skimage :244)
+//   K4c upsample 2 cc_up[a][b] = sum_k0 D1[k0][b] e^{+2 pi i (a-off0) f0[k0]}   (16 k0-slices per block, fixed order)
+//   K4d argmax |cc_up| in row-major order (skimage :244)
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -46,7 +47,7 @@ inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
 
 // Workspace carve-up, identical on host (sizes) and device (pointers).
 struct Layout {
-    int64_t tw0, tw1, up0, up1, spectra, amps, rowmax, d1, peak, total;
+    int64_t tw0, tw1, up0, up1, spectra, amps, rowmax, d1, ccup, peak, total;
     int n0, n1, n1h, region, up;
     int64_t per_pair_spec;
 };
@@ -76,6 +77,8 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     off += align16((int64_t)n_pairs * ((n0 + 1) / 2) * 16);   // (|cc| value, flat index) per row pair
     L.d1 = off;
     off += align16((int64_t)n_pairs * n0 * L.region * 16);
+    L.ccup = off;
+    off += align16((int64_t)n_pairs * L.region * L.region * 16);   // upsampled correlation, R x R complex
     L.peak = off;
     off += align16((int64_t)n_pairs * 16);                    // 4 ints per pair
     L.total = off;
@@ -550,59 +553,58 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4c: cc_up[a][b] = sum_{k0} D1[k0][b] * exp(+2 pi i (a - off0) f0[k0]); argmax |.| row-major
+// K4c: cc_up[a][b] = sum_{k0} D1[k0][b] * exp(+2 pi i (a - off0) f0[k0])   (one block per (a, pair))
+// The k0 range is cut into 16 slices summed by 16 thread groups and combined in slice order, so the
+// result does not depend on scheduling.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upsample_peak_kernel(RegParams P) {
+__global__ __launch_bounds__(256) void upsample_cols_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, R = L.region, up = L.up;
-    const int pair = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int a = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
     const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
     const int off0 = R / 2 - pk[0] * up;
     const cplx *D1 = reinterpret_cast<const cplx *>(P.ws + L.d1) + (int64_t)pair * n0 * R;
     const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up0);
     const int M = n0 * up;
-    Best best = {-1.0, (long long)1 << 62, 0};
-    double bre = 0.0, bim = 0.0;
-    for (int o = tid; o < R * R; o += nt) {
-        const int a = o / R, b = o - a * R;
-        const long long ma = a - off0;
+    const long long ma = a - off0;
+    __shared__ cplx part[16][16];
+    cplx *out = reinterpret_cast<cplx *>(P.ws + L.ccup) + ((int64_t)pair * R + a) * R;
+    for (int b0 = 0; b0 < R; b0 += 16) {   // R = 15 for u = 10: one pass
+        const int b = b0 + (tid & 15), slice = tid >> 4;
         cplx acc = {0.0, 0.0};
-        for (int k0 = 0; k0 < n0; ++k0) {
-            const cplx e = E[posmod(ma * signed_freq(k0, n0), M)];
-            acc = cadd(acc, cmul(D1[(int64_t)k0 * R + b], e));
+        if (b < R) {
+            const int k_lo = (int)((int64_t)n0 * slice / 16), k_hi = (int)((int64_t)n0 * (slice + 1) / 16);
+            for (int k0 = k_lo; k0 < k_hi; ++k0) {
+                const cplx e = E[posmod(ma * signed_freq(k0, n0), M)];
+                acc = cadd(acc, cmul(D1[(int64_t)k0 * R + b], e));
+            }
         }
-        const Best cand = make_best(hypot(acc.re, acc.im), o);
-        const Best nb = better(best, cand);
-        if (nb.idx == o) {
-            bre = acc.re;
-            bim = acc.im;
+        part[slice][tid & 15] = acc;
+        __syncthreads();
+        if (tid < 16 && b0 + tid < R) {
+            cplx sum = part[0][tid];
+            for (int sl = 1; sl < 16; ++sl) sum = cadd(sum, part[sl][tid]);
+            out[b0 + tid] = sum;
         }
-        best = nb;
+        __syncthreads();
     }
-    // block argmax; the winner's complex value travels with it
-    __shared__ double sre[256], sim[256], sv[256];
-    __shared__ long long si[256];
-    __shared__ int sn[256];
-    sre[tid] = bre;
-    sim[tid] = bim;
-    sv[tid] = best.v;
-    si[tid] = best.idx;
-    sn[tid] = best.nan;
-    __syncthreads();
+}
+
+// K4d: argmax |cc_up| in row-major order (skimage :244), one block per pair
+__global__ __launch_bounds__(256) void upsample_peak_kernel(RegParams P) {
+    const Layout &L = P.L;
+    const int R = L.region;
+    const int pair = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const cplx *cc = reinterpret_cast<const cplx *>(P.ws + L.ccup) + (int64_t)pair * R * R;
+    Best best = {-1.0, (long long)1 << 62, 0};
+    for (int o = tid; o < R * R; o += nt) best = better(best, make_best(hypot(cc[o].re, cc[o].im), o));
+    best = block_best(best, tid, nt);
     if (tid == 0) {
-        int w = 0;
-        Best r = {sv[0], si[0], sn[0]};
-        for (int t = 1; t < nt; ++t) {
-            const Best c = {sv[t], si[t], sn[t]};
-            const Best nb = better(r, c);
-            if (nb.idx != r.idx) w = t;
-            r = nb;
-        }
         sq_pair_result &res = P.results[pair];
-        res.fine[0] = (int)(r.idx / R);
-        res.fine[1] = (int)(r.idx % R);
-        res.ccmax_re = sre[w];
-        res.ccmax_im = sim[w];
+        res.fine[0] = (int)(best.idx / R);
+        res.fine[1] = (int)(best.idx % R);
+        res.ccmax_re = cc[best.idx].re;
+        res.ccmax_im = cc[best.idx].im;
     }
 }
 
@@ -709,6 +711,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
         hipLaunchKernelGGL(upsample_rows_kernel, dim3(L.n0, a->n_pairs), dim3(pick_threads(L.n1)), 0, s, P);
+        hipLaunchKernelGGL(upsample_cols_kernel, dim3(L.region, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     }
     hipError_t e = hipGetLastError();

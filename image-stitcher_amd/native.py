@@ -288,31 +288,43 @@ def tile_minmax(tiles, stream=None, tile_ptrs=None, shape=None, np_dtype=None):
     return out
 
 
-def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
-                   normalization: int = SQ_NORM_PHASE, stream=None, tile_ptrs=None, shape=None,
-                   np_dtype=None) -> np.ndarray:
-    """Batched phase cross-correlation of crop pairs.  ``tiles`` [N, H, W] device stack (or a
-    pointer table + shape + dtype), ``pairs`` PAIR_DTYPE host array.  Returns a RESULT_DTYPE host
-    array (synchronises)."""
+class PendingRegistration:
+    """Results of an enqueued sq_register_pairs; ``fetch()`` synchronises and returns them."""
+
+    def __init__(self, res_dev, keep, n):
+        self._res, self._keep, self._n = res_dev, keep, n
+
+    def fetch(self) -> np.ndarray:
+        if self._n == 0:
+            return np.zeros(0, dtype=RESULT_DTYPE)
+        out = self._res.cpu().numpy().view(RESULT_DTYPE).copy()
+        self._keep = None
+        return out
+
+
+def register_pairs_async(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
+                         normalization: int = SQ_NORM_PHASE, stream=None, tile_ptrs=None, shape=None,
+                         np_dtype=None) -> PendingRegistration:
+    """Enqueue batched phase cross-correlation of crop pairs and return without synchronising.
+    ``tiles`` [N, H, W] device stack (or a pointer table + shape + dtype), ``pairs`` PAIR_DTYPE."""
     import torch
     L = lib()
     ptrs, base, stride, n, h, w, dt = _tile_table(tiles, tile_ptrs, shape, np_dtype)
     device = tile_ptrs.device if tile_ptrs is not None else tiles.device
     pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
     npairs = len(pairs)
-    out = np.zeros(npairs, dtype=RESULT_DTYPE)
     if npairs == 0:
-        return out
+        return PendingRegistration(None, None, 0)
     ws_bytes = L.sq_register_workspace_bytes(npairs, n0, n1, upsample_factor)
     if ws_bytes < 0:
         raise NativeError(f"sq_register_workspace_bytes failed: {L.sq_last_error().decode()}")
-    if len(pairs) and (min(pairs['ref_tile'].min(), pairs['mov_tile'].min()) < 0 or
-                       max(pairs['ref_tile'].max(), pairs['mov_tile'].max()) >= n):
+    if min(pairs['ref_tile'].min(), pairs['mov_tile'].min()) < 0 or \
+            max(pairs['ref_tile'].max(), pairs['mov_tile'].max()) >= n:
         raise ValueError("pair refers to a tile outside the table")
-    if len(pairs) and ((pairs['ref_y0'] < 0).any() or (pairs['ref_x0'] < 0).any() or (pairs['mov_y0'] < 0).any()
-                       or (pairs['mov_x0'] < 0).any() or (pairs['ref_y0'] + n0 > h).any()
-                       or (pairs['mov_y0'] + n0 > h).any() or (pairs['ref_x0'] + n1 > w).any()
-                       or (pairs['mov_x0'] + n1 > w).any()):
+    if ((pairs['ref_y0'] < 0).any() or (pairs['ref_x0'] < 0).any() or (pairs['mov_y0'] < 0).any()
+            or (pairs['mov_x0'] < 0).any() or (pairs['ref_y0'] + n0 > h).any()
+            or (pairs['mov_y0'] + n0 > h).any() or (pairs['ref_x0'] + n1 > w).any()
+            or (pairs['mov_x0'] + n1 > w).any()):
         raise ValueError("crop reaches outside its tile")
     ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=device)
     pairs_dev = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(device)
@@ -333,7 +345,15 @@ def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_
     a.workspace_dev = ws.data_ptr()
     a.workspace_bytes = ws.numel()
     _check(L.sq_register_pairs(C.byref(a), _stream_ptr(stream)), 'sq_register_pairs')
-    return res_dev.cpu().numpy().view(RESULT_DTYPE).copy()
+    return PendingRegistration(res_dev, (ws, pairs_dev, minmax, tiles, tile_ptrs), npairs)
+
+
+def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,
+                   normalization: int = SQ_NORM_PHASE, stream=None, tile_ptrs=None, shape=None,
+                   np_dtype=None) -> np.ndarray:
+    """register_pairs_async + fetch: returns a RESULT_DTYPE host array (synchronises)."""
+    return register_pairs_async(tiles, minmax, pairs, n0, n1, upsample_factor, normalization, stream,
+                                tile_ptrs, shape, np_dtype).fetch()
 
 
 def synth_tiles(desc: np.ndarray, tile_h: int, tile_w: int, noise_amp: int, np_dtype, device, out=None, stream=None):

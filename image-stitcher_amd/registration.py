@@ -125,26 +125,29 @@ def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], y
     minmax = native.tile_minmax(None, tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
     code = _norm_code(normalization)
 
-    def run(pairs, make):
+    def launch(pairs, make):
         rows = []
         for a, b in pairs:
             p, n0, n1 = make(local[a], local[b], height, width, mx if make is horizontal_pair else my)
             rows.append(p)
-        res = native.register_pairs(None, minmax, np.array(rows, dtype=native.PAIR_DTYPE), n0, n1, 10, code,
-                                    tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
-        return shifts_from_results(res, 10)[0], n0, n1
+        pending = native.register_pairs_async(None, minmax, np.array(rows, dtype=native.PAIR_DTYPE), n0, n1, 10, code,
+                                              tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
+        return pending, n0, n1
 
-    if hp:
-        s, n0, n1 = run(hp, horizontal_pair)
-        out.h_shift = horizontal_shift_from(s[0], n1)
+    # both batches are enqueued before the single synchronising fetch
+    hq = launch(hp, horizontal_pair) if hp else None
+    vq = launch(vp, vertical_pair) if vp else None
+    if hq:
+        s = shifts_from_results(hq[0].fetch(), 10)[0]
+        out.h_shift = horizontal_shift_from(s[0], hq[2])
         if len(hp) > 1:
-            out.h_shift_rev = horizontal_shift_from(s[1], n1)
+            out.h_shift_rev = horizontal_shift_from(s[1], hq[2])
             out.h_shift_rev_odd = int(ri % 2 == 0)
     if scan_pattern == 'S-Pattern' and out.h_shift_rev is None:
         out.h_shift_rev = (0, 0)
-    if vp:
-        s, n0, n1 = run(vp, vertical_pair)
-        out.v_shift = vertical_shift_from(s[0], n0)
+    if vq:
+        s = shifts_from_results(vq[0].fetch(), 10)[0]
+        out.v_shift = vertical_shift_from(s[0], vq[1])
     return out
 
 
