@@ -336,51 +336,132 @@ __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P,
 
 // ---------------------------------------------------------------------------------------------
 // feather mode (extension; definition = oracle/stitch_oracle.py fuse_plane_feather)
-//   out = sum_i w_i v_i / sum_i w_i, float32, tiles in write order,
+//   voxels covered by ONE tile:  out = v
+//   voxels covered by several:   out = sum_i w_i v_i / sum_i w_i   (float32, tiles in write order,
+//                                multiply and add separate like numpy: -ffp-contract=off)
 //   w_i = min(sx+1, W-sx, sy+1, H-sy) in the tile's own coordinates,
 //   v_i = tile / float32(flatfield) when a flatfield is given (no clip).
-// Compiled with -ffp-contract=off: multiply and add stay separate like numpy's.
+//   integer canvases: rint + clip.  Uncovered voxels: 0.
+// Same skeleton as the overwrite kernel: persistent grid over (plane, item), one wave per canvas
+// row, 8 pixels per lane per step with stores aligned to the 8-pixel group, row edges one pixel
+// per lane.  The refs of an item are wave-uniform, so the per-ref loop runs on scalar registers.
 // ---------------------------------------------------------------------------------------------
+template <typename T, int FLAT>
+__device__ __forceinline__ float feather_value(const FuseParams &P, const T *tile, const char *flat, int y, int x) {
+    float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
+    if (FLAT && flat) {
+        const char *g = flat + ((int64_t)y * P.tile_w + x) * (FLAT == 2 ? 8 : 4);
+        v = __fdiv_rn(v, FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g));
+    }
+    return v;
+}
+
+template <typename OutT>
+__device__ __forceinline__ OutT feather_out(float o) {
+    if (sizeof(OutT) == 4) return (OutT)o;
+    const float hi = sizeof(OutT) == 1 ? 255.0f : 65535.0f;
+    return (OutT)fminf(fmaxf(rintf(o), 0.0f), hi);
+}
+
 template <typename T, typename OutT, int FLAT>
 __global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
                                                             const int64_t n_work) {
+    constexpr int VEC = 8;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    constexpr int FSZ = FLAT == 2 ? 8 : 4;
     for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
         const int plane = (int)(work / n_items);
         const Item it = P.items[work - plane * n_items];
         const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+        const int nref = it.nref;
         OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
         const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
-        const int nref = it.nref;
         for (int r = wave; r < rows; r += 4) {
             OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
-            for (int p = lane; p < n; p += 64) {
-                float acc = 0.0f, wsum = 0.0f;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(OutT)) & (VEC - 1));
+            const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+            // ---- whole 8-pixel groups ------------------------------------------------------
+            for (int v = v_first + lane; v < v_end; v += 64) {
+                const int p0 = v * VEC - mis;
+                float acc[VEC], wsum[VEC], last[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = wsum[e] = last[e] = 0.0f;
                 for (int k = 0; k < nref; ++k) {
                     const Ref rf = P.refs[it.a + k];
                     const T *tile = tile_ptr<T>(P, plane, rf.tile);
                     const int y = rf.src_y + it.b + r;
-                    const int x = rf.src_x + it.c + p;
-                    float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
-                    if (FLAT && flat) {
-                        const char *g = flat + ((int64_t)y * P.tile_w + x) * FSZ;
-                        const float gf = FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g);
-                        v = __fdiv_rn(v, gf);
+                    const int x0 = rf.src_x + it.c + p0;
+                    const T *src = tile + (int64_t)y * P.tile_pitch + x0;
+                    float px[VEC];
+                    if (sizeof(T) == 2) {
+                        const u32x4 raw = ldg<U32x4U>(src);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) px[e] = (float)Pix<uint16_t>::get(raw, e);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) px[e] = (float)ldg_s<T>(src + e);
                     }
+                    if (FLAT && flat) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const char *g = flat + ((int64_t)y * P.tile_w + x0 + e) * (FLAT == 2 ? 8 : 4);
+                            px[e] = __fdiv_rn(px[e], FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g));
+                        }
+                    }
+                    const int wy = min(y + 1, P.tile_h - y);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const int x = x0 + e;
+                        const float w = (float)min(min(x + 1, P.tile_w - x), wy);
+                        acc[e] = __fadd_rn(acc[e], __fmul_rn(w, px[e]));
+                        wsum[e] = __fadd_rn(wsum[e], w);
+                        last[e] = px[e];
+                    }
+                }
+                OutT o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    o[e] = feather_out<OutT>(nref == 1 ? last[e] : (nref ? __fdiv_rn(acc[e], wsum[e]) : 0.0f));
+                if (sizeof(OutT) == 2) {
+                    u32x4 out;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) out[q] = (uint32_t)(uint16_t)o[2 * q] | ((uint32_t)(uint16_t)o[2 * q + 1] << 16);
+                    stg_nt(drow + p0, out);
+                } else if (sizeof(OutT) == 4) {
+                    u32x4 lo, hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        lo[q] = __float_as_uint((float)o[q]);
+                        hi[q] = __float_as_uint((float)o[4 + q]);
+                    }
+                    stg_nt(drow + p0, lo);
+                    stg_nt(drow + p0 + 4, hi);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) stg_s<OutT>(drow + p0 + e, o[e]);
+                }
+            }
+            // ---- row edges: one pixel per lane ---------------------------------------------
+            const int head_end = min(n, v_first * VEC - mis);
+            const int tail_start = max(head_end, v_end * VEC - mis);
+            int p = -1;
+            if (lane < VEC) {
+                if (lane < head_end) p = lane;
+            } else if (lane < 2 * VEC) {
+                if (tail_start + (lane - VEC) < n) p = tail_start + (lane - VEC);
+            }
+            if (p >= 0) {
+                float acc = 0.0f, wsum = 0.0f, last = 0.0f;
+                for (int k = 0; k < nref; ++k) {
+                    const Ref rf = P.refs[it.a + k];
+                    const int y = rf.src_y + it.b + r, x = rf.src_x + it.c + p;
+                    const float v = feather_value<T, FLAT>(P, tile_ptr<T>(P, plane, rf.tile), flat, y, x);
                     const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
                     acc = __fadd_rn(acc, __fmul_rn(w, v));
                     wsum = __fadd_rn(wsum, w);
+                    last = v;
                 }
-                float o = wsum > 0.0f ? __fdiv_rn(acc, wsum) : 0.0f;
-                if (sizeof(OutT) == 4) {
-                    stg_s<float>(reinterpret_cast<float *>(drow) + p, o);
-                } else {
-                    const float hi = sizeof(OutT) == 1 ? 255.0f : 65535.0f;
-                    o = fminf(fmaxf(rintf(o), 0.0f), hi);
-                    stg_s<OutT>(drow + p, (OutT)o);
-                }
+                stg_s<OutT>(drow + p, feather_out<OutT>(nref == 1 ? last : (nref ? __fdiv_rn(acc, wsum) : 0.0f)));
             }
         }
     }

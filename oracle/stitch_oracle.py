@@ -434,25 +434,30 @@ def feather_weight(h: int, w: int) -> np.ndarray:
 
 def fuse_plane_feather(tiles, rects: np.ndarray, canvas_h: int, canvas_w: int,
                        flatfield: Optional[np.ndarray] = None, out_dtype=np.float32) -> np.ndarray:
-    """EXTENSION (not in the reference): distance-weighted blend
-    out = sum_i w_i v_i / sum_i w_i in float32, tiles accumulated in write order; the
-    flatfield divide (float32, no clip) is applied to v_i first.  Integer outputs round to
-    nearest-even and clip.  Uncovered voxels are 0."""
+    """EXTENSION (not in the reference): distance-weighted blend.  Where ONE tile covers a voxel
+    the output is that tile's value; where several do, out = sum_i w_i v_i / sum_i w_i in float32,
+    tiles accumulated in write order.  The flatfield divide (float32, no clip) is applied to v_i
+    first.  Integer outputs round to nearest-even and clip.  Uncovered voxels are 0."""
     tile_h, tile_w = tiles[0].shape
     wfull = feather_weight(tile_h, tile_w)
     acc = np.zeros((canvas_h, canvas_w), dtype=np.float32)
     wsum = np.zeros((canvas_h, canvas_w), dtype=np.float32)
+    last = np.zeros((canvas_h, canvas_w), dtype=np.float32)
+    count = np.zeros((canvas_h, canvas_w), dtype=np.int32)
     for tile, (sy, sx, h, w, dy, dx) in zip(tiles, clip_rects(np.asarray(rects), canvas_h, canvas_w)):
         if h <= 0 or w <= 0:
             continue
         v = tile[sy:sy + h, sx:sx + w].astype(np.float32)
         if flatfield is not None:
-            v = v / flatfield[sy:sy + h, sx:sx + w].astype(np.float32)
+            with np.errstate(all='ignore'):
+                v = v / flatfield[sy:sy + h, sx:sx + w].astype(np.float32)
         wt = wfull[sy:sy + h, sx:sx + w]
         acc[dy:dy + h, dx:dx + w] += wt * v
         wsum[dy:dy + h, dx:dx + w] += wt
+        last[dy:dy + h, dx:dx + w] = v
+        count[dy:dy + h, dx:dx + w] += 1
     with np.errstate(all='ignore'):
-        out = np.where(wsum > 0, acc / wsum, np.float32(0)).astype(np.float32)
+        out = np.where(count > 1, acc / wsum, np.where(count == 1, last, np.float32(0))).astype(np.float32)
     if np.issubdtype(np.dtype(out_dtype), np.integer):
         info = np.iinfo(out_dtype)
         return np.clip(np.rint(out), info.min, info.max).astype(out_dtype)

@@ -131,11 +131,9 @@ def test_feather_matches_oracle_definition(out_dtype, with_flat):
                          out_dtype=out_dtype)
     want = O.fuse_plane_feather(list(tiles[0]), rects, ch, cw, flat, out_dtype=np.dtype(out_dtype).type)
     assert plan.max_refs >= 2
-    if out_dtype == 'float32':
-        np.testing.assert_allclose(got[0], want, rtol=1e-5, atol=0)   # north_star: 1e-5 relative
-    else:
-        assert np.abs(got[0].astype(np.int64) - want.astype(np.int64)).max() <= 1
-        assert (got[0] != want).mean() < 1e-3     # only .5 ties may differ
+    # north_star asks for 1e-5 relative; the kernel keeps numpy's operation order, so it is exact
+    np.testing.assert_allclose(got[0], want, rtol=1e-5, atol=0)
+    np.testing.assert_array_equal(got[0], want)
 
 
 def test_synth_device_generator_equals_numpy():
