@@ -96,6 +96,8 @@ class GridSpec:
     rev_jy: Optional[int] = None     # S-Pattern: y drift per column step on reversed rows
     noise: int = 200
     base: int = 4096
+    rgb_channels: Sequence[str] = ()   # channels written as H x W x 3 uint8 files (dtype must be uint8)
+    missing: Sequence[Tuple[int, int, int, int]] = ()   # (fov, z, channel index, t) files NOT written (ragged input)
     sensor_pixel_size_um: float = 5.0
     magnification: float = 10.0
     tube_lens_mm: float = 180.0
@@ -195,8 +197,13 @@ def write_acquisition(spec: GridSpec, root: str) -> List[str]:
                     for z in range(spec.nz):
                         lines.append(f'{region},{fov},{z},{x_mm!r},{y_mm!r},{z * spec.dz_um!r}')
                         for ci, ch in enumerate(spec.channels):
+                            if (fov, z, ci, t) in set(map(tuple, spec.missing)):
+                                continue
                             p = os.path.join(tdir, f'{region}_{fov}_{z}_{channel_file_token(ch)}.tiff')
-                            write_tiff(p, spec.tile(r, c, ri, t, z, ci))
+                            img = spec.tile(r, c, ri, t, z, ci)
+                            if ch in spec.rgb_channels:   # three different planes of the same scene family
+                                img = np.stack([img, spec.tile(r, c, ri, t, z, ci + 17), spec.tile(r, c, ri, t, z, ci + 31)], axis=-1)
+                            write_tiff(p, img)
                             paths.append(p)
         with open(os.path.join(tdir, 'coordinates.csv'), 'w') as fh:
             fh.write('\n'.join(lines) + '\n')

@@ -152,6 +152,7 @@ class Acquisition:
         self.timepoints: List[str] = []
         self.regions: List[str] = []
         self.channel_names: List[str] = []
+        self.monochrome_channels: List[str] = []
         self.num_z = 1
         self.pixel_size_um = 0.0
         self.pixel_binning = 1
@@ -205,9 +206,20 @@ def parse_acquisition(folder: str, read_image) -> Acquisition:
     acq.regions = sorted(regions)
     acq.channel_names = sorted(channels)
     acq.num_z = max_z + 1
-    first = read_image(next(iter(acq.meta.values()))['filepath'])
+    first_rec = next(iter(acq.meta.values()))
+    first = read_image(first_rec['filepath'])
     acq.dtype = first.dtype.type
     acq.input_height, acq.input_width = first.shape[:2]
+    # RGB files become three monochrome channels (stitcher.py:238-246); like the reference this
+    # needs the first (t, region, fov, z) to exist for every channel (KeyError otherwise)
+    for channel in acq.channel_names:
+        key = (first_rec['t'], first_rec['region'], first_rec['fov_idx'], first_rec['z_level'], channel)
+        img = read_image(acq.meta[key]['filepath'])
+        if img.ndim == 3 and img.shape[2] == 3:
+            base = channel.split('_')[0]
+            acq.monochrome_channels.extend([f"{base}_R", f"{base}_G", f"{base}_B"])
+        else:
+            acq.monochrome_channels.append(channel)
     return acq
 
 
@@ -332,8 +344,14 @@ def plan_region(acq: Acquisition, t, region, use_registration, h_shift=(0, 0), v
         x_px, y_px, top, bottom, left, right = tile_rect(
             info, xs, ys, acq.input_width, acq.input_height, acq.pixel_size_um, use_registration,
             h_shift, v_shift, h_shift_rev, h_shift_rev_odd, plan.canvas_w, plan.canvas_h)
-        plan.files.append(dict(filepath=info['filepath'], c=acq.channel_names.index(channel), z=z, fov=fov,
-                               x_px=x_px, y_px=y_px, top=top, bottom=bottom, left=left, right=right))
+        if channel in acq.monochrome_channels:
+            targets = [(acq.monochrome_channels.index(channel), -1)]
+        else:   # RGB file: one placement per colour plane (stitcher.py:551-556)
+            base = channel.split('_')[0]
+            targets = [(acq.monochrome_channels.index(f"{base}_{col}"), i) for i, col in enumerate('RGB')]
+        for c_idx, rgb in targets:
+            plan.files.append(dict(filepath=info['filepath'], c=c_idx, rgb=rgb, z=z, fov=fov,
+                                   x_px=x_px, y_px=y_px, top=top, bottom=bottom, left=left, right=right))
     return plan
 
 
@@ -386,9 +404,11 @@ def stitch_region(acq: Acquisition, t, region, read_image, use_registration=Fals
     plan = plan_region(acq, t, region, use_registration, shifts.get('h_shift', (0, 0)),
                        shifts.get('v_shift', (0, 0)), shifts.get('h_shift_rev'),
                        shifts.get('h_shift_rev_odd', 0), 1)
-    canvas = np.zeros((1, len(acq.channel_names), acq.num_z, plan.canvas_h, plan.canvas_w), dtype=acq.dtype)
+    canvas = np.zeros((1, len(acq.monochrome_channels), acq.num_z, plan.canvas_h, plan.canvas_w), dtype=acq.dtype)
     for f in plan.files:
         tile = read_image(f['filepath'])
+        if f['rgb'] >= 0:
+            tile = tile[:, :, f['rgb']]
         if apply_flat:
             tile = apply_flatfield(tile, (flatfields or {}).get(f['c']), acq.dtype)
         place_tile(canvas, f['c'], f['z'], tile, f['x_px'], f['y_px'], f['top'], f['bottom'], f['left'], f['right'])

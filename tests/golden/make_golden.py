@@ -291,6 +291,13 @@ def main():
     run_case('reg_multi', G(rows=2, cols=2, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=18,
                             regions=('A1', 'B2'), nt=2),
              use_registration=True)
+    run_case('reg_ragged', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=19, channels=ch2, nz=2,
+                             missing=((6, 0, 1, 0), (8, 1, 1, 0), (2, 1, 0, 0))),
+             use_registration=True)
+    run_case('coord_rgb', G(rows=2, cols=2, tile_h=64, tile_w=96, ov_y=16, ov_x=24, seed=20, dtype='uint8',
+                            channels=('BF LED matrix full_RGB', 'Fluorescence 488 nm Ex'),
+                            rgb_channels=('BF LED matrix full_RGB',)),
+             use_registration=False)
     run_case('reg_3x3_512', G(rows=3, cols=3, tile_h=512, tile_w=512, ov_y=77, ov_x=77, seed=2000),
              use_registration=True, keep_canvas=False,
              windows=[(0, 0, 420, 420, 64, 64), (0, 0, 0, 0, 16, 128), (0, 0, 860, 880, 80, 80)])

@@ -28,8 +28,9 @@ def load_case(name):
 
 def spec_of(info):
     d = dict(info['spec'])
-    for k in ('channels', 'regions'):
-        d[k] = tuple(d[k])
+    for k in ('channels', 'regions', 'rgb_channels'):
+        d[k] = tuple(d.get(k, ()))
+    d['missing'] = tuple(tuple(m) for m in d.get('missing', ()))
     return synth.GridSpec(**d)
 
 

@@ -89,7 +89,7 @@ def test_region_case(name, tmp_path):
     acq = O.parse_acquisition(root, read_image)
     p = info['params']
     assert acq.regions == info['regions']
-    assert acq.channel_names == info['channels']
+    assert acq.monochrome_channels == info['channels']
     assert acq.num_z == info['num_z']
     assert str(np.dtype(acq.dtype)) == info['dtype']
     shifts = None
@@ -107,7 +107,7 @@ def test_region_case(name, tmp_path):
                                 p['registration_channel'], p['registration_z_level'],
                                 spec.scan_pattern, normalization='phase')
         assert list(ph['h_shift']) == info['h_shift'] and list(ph['v_shift']) == info['v_shift']
-    flats = flatfields_for(info, len(acq.channel_names))
+    flats = flatfields_for(info, len(acq.monochrome_channels))
     grid_dim = 1
     if len(acq.regions) > 1:
         grid_dim = max(len(set(r[0] for r in acq.regions)), len(set(r[1:] for r in acq.regions)))
@@ -117,7 +117,7 @@ def test_region_case(name, tmp_path):
                              *( [shifts['h_shift'], shifts['v_shift'], shifts.get('h_shift_rev'),
                                  shifts.get('h_shift_rev_odd', 0)] if shifts else [(0, 0), (0, 0), None, 0]),
                              grid_dim)
-        assert [1, len(acq.channel_names), acq.num_z, plan.canvas_h, plan.canvas_w] == cinfo['shape']
+        assert [1, len(acq.monochrome_channels), acq.num_z, plan.canvas_h, plan.canvas_w] == cinfo['shape']
         assert plan.levels == cinfo['num_pyramid_levels']
         gold_pl = arrays[f'{key}_placements']
         mine = np.array([[f['c'], f['z'], f['x_px'], f['y_px']] for f in plan.files])
