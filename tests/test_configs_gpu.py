@@ -1,0 +1,115 @@
+"""BASELINE.json's configurations as parity cases (scaled where the full size would not finish in
+seconds on the oracle), plus size-independent properties at the full tile size."""
+import numpy as np
+import pytest
+
+from image_stitcher_amd import native, placement, registration, sharding, synth
+from image_stitcher_amd.stitcher import Stitcher
+from image_stitcher_amd.stitcher_parameters import StitchingParameters
+from image_stitcher_amd.tiffio import read_image
+from oracle import stitch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _device_tiles(spec, z=0, ch=0, region_idx=0, t=0):
+    g = spec.rows * spec.cols
+    desc = np.zeros(g, dtype=native.SYNTH_DTYPE)
+    for r in range(spec.rows):
+        for c in range(spec.cols):
+            oy, ox = spec.origin(r, c)
+            desc[r * spec.cols + c] = (spec.scene_seed(region_idx, t, z, ch) % 2 ** 64,
+                                       spec.noise_seed(region_idx, t, z, ch, spec.fov_index(r, c)) % 2 ** 64, oy, ox)
+    return native.synth_tiles(desc, spec.tile_h, spec.tile_w, spec.noise, spec.dtype, _dev())
+
+
+def test_config4_geometry_32x32_grid_two_planes():
+    """32x32 grid (1024 tiles, the planner's largest configuration) at 1/16 tile size, planes
+    dealt to two 'ranks' block-cyclically: the union equals the oracle's canvases."""
+    import torch
+    spec = synth.GridSpec(rows=32, cols=32, tile_h=128, tile_w=128, ov_y=16, ov_x=16, seed=4000)
+    shifts = placement.Shifts((3, -16), (-16, -2))
+    order = placement.filename_order([spec.fov_index(r, c) for r in range(32) for c in range(32)])
+    order_rc = [divmod(i, 32) for i in order]
+    rects = placement.grid_rects(32, 32, 128, 128, shifts, order=order_rc)
+    wc, hc = placement.canvas_size(32, 32, 128, 128, use_registration=True, shifts=shifts)
+    plan = native.FusePlan(rects, 128, 128, hc, wc)
+    n_planes = 3
+    idx = torch.tensor(order, device=_dev())
+    # torch has no uint16 gather: reorder through an int16 view
+    tiles = torch.stack([_device_tiles(spec, z=p).view(torch.int16)[idx] for p in range(n_planes)]).view(torch.uint16)
+    canvas = torch.zeros((n_planes, hc, wc), dtype=torch.uint16, device=_dev())
+    for rank in range(2):
+        for p in sharding.block_cyclic(n_planes, rank, 2):
+            native.fuse_planes(plan, tiles[p:p + 1].contiguous(), canvas[p:p + 1])
+    torch.cuda.synchronize()
+    got = canvas.cpu().numpy()
+    for p in range(n_planes):
+        host = tiles[p].cpu().numpy()
+        np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(host), rects, hc, wc))
+
+
+def test_config2_full_size_properties():
+    """8x8 grid of 2048^2 tiles with -r (config 2) at full size: registration of every pair agrees
+    with the planted drift, and fusion satisfies size-independent properties -- every tile's
+    interior appears verbatim at its placement, uncovered rows are zero, and a second launch into
+    a poisoned canvas gives the identical result (every voxel is written exactly once)."""
+    import torch
+    spec = synth.GridSpec(rows=8, cols=8, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, seed=2000)
+    tiles = _device_tiles(spec)
+    xs = [spec.stage_mm(0, c)[0] for c in range(8)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(8)]
+    shifts = registration.register_grid_center(tiles, 8, 8, xs, ys, spec.pixel_size_um, spec.pixel_binning, 'phase')
+    assert (shifts.h_shift, shifts.v_shift) == ((3, -244), (-244, -2))
+    mx, my = placement.registration_crop_widths(xs, ys, 2048, 2048, spec.pixel_size_um, spec.pixel_binning)
+    (hp, (h0, h1)), (vp, (v0, v1)) = registration.all_pairs(8, 8, 2048, 2048, mx, my)
+    hs, _, _ = registration.register_pairs(tiles, hp, h0, h1, 10, 'phase')
+    vs, _, _ = registration.register_pairs(tiles, vp, v0, v1, 10, 'phase')
+    truth_h = np.array([3.0, 256 - 244.0]); truth_v = np.array([256 - 244.0, -2.0])
+    assert np.sqrt(((hs - truth_h) ** 2).mean()) <= 0.5 and np.sqrt(((vs - truth_v) ** 2).mean()) <= 0.5   # shift RMSE bar
+    rects = placement.grid_rects(8, 8, 2048, 2048, shifts)
+    wc, hc = placement.canvas_size(8, 8, 2048, 2048, use_registration=True, shifts=shifts)
+    plan = native.FusePlan(rects, 2048, 2048, hc, wc)
+    canvas = torch.full((1, hc, wc), 0xAAAA, dtype=torch.uint16, device=_dev())
+    native.fuse_planes(plan, tiles[None], canvas)
+    first = canvas.clone()
+    canvas.fill_(0x5555)
+    native.fuse_planes(plan, tiles[None], canvas)
+    assert torch.equal(first.view(torch.int16), canvas.view(torch.int16))
+    # voxel census: covered voxels are >= 800 (the generator's floor), the rest are exactly zero
+    nz = int((canvas.view(torch.int16) != 0).sum())
+    assert nz == plan.covered_voxels
+    for i in (0, 9, 27, 63):
+        sy, sx, h, w, dy, dx = rects[i]
+        np.testing.assert_array_equal(canvas[0, dy + 300:dy + 364, dx + 300:dx + 364].cpu().numpy(),
+                                      tiles[i, sy + 300:sy + 364, sx + 300:sx + 364].cpu().numpy())
+
+
+def test_config5_hcs_plate_scaled(tmp_path):
+    """HCS plate (config 5) scaled down: wells x timepoints, 5x5 tiles, 3 channels; per-well
+    registration (the north-star extension) and fusion against the oracle for every (t, well)."""
+    wells = ('A1', 'A2', 'B1')
+    spec = synth.GridSpec(rows=5, cols=5, tile_h=96, tile_w=128, ov_y=24, ov_x=32, seed=5000, regions=wells, nt=2,
+                          channels=synth.DEFAULT_CHANNELS[:3])
+    root = str(tmp_path / 'plate')
+    synth.write_acquisition(spec, root)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization='phase')
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    acq = O.parse_acquisition(root, read_image)
+    assert st.regions == list(wells) == acq.regions and st.num_t == 2
+    table = []
+    for t in st.timepoints:
+        for well in st.regions:
+            st.calculate_shifts(t, well)                       # per-well registration
+            want = O.calculate_shifts(acq, t, well, read_image, '', 0, 'Unidirectional', 'phase')
+            assert (st.h_shift, st.v_shift) == (want['h_shift'], want['v_shift'])
+            table.append(sharding.shifts_to_row(st._shifts()))
+            canvas = st.stitch_region(int(t), well)
+            np.testing.assert_array_equal(canvas, O.stitch_region(acq, t, well, read_image, True, want))
+    assert np.stack(table).shape == (6, sharding.SHIFT_ROW)
