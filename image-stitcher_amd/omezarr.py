@@ -92,9 +92,10 @@ def write_ome_zarr(path: str, image: np.ndarray, *, pixel_size_um: float, dz_um:
                      {'name': 'y', 'type': 'space', 'unit': 'micrometer'},
                      {'name': 'x', 'type': 'space', 'unit': 'micrometer'}],
             'datasets': datasets}],
-        'omero': {'name': name, 'version': '0.4', 'channels': [
+        'omero': {'id': 1, 'name': name, 'version': '0.4', 'channels': [
             {'label': n, 'color': f'{(channel_colors[i] if i < len(channel_colors) else 0xFFFFFF):06X}',
-             'window': {'start': 0, 'end': int(info.max) if info else 1, 'min': 0, 'max': int(info.max) if info else 1}}
+             'window': {'start': 0, 'end': int(info.max) if info else 1, 'min': 0, 'max': int(info.max) if info else 1},
+             'active': True, 'coefficient': 1, 'family': 'linear'}
             for i, n in enumerate(channel_names)]},
     }
     _write_json(os.path.join(path, '.zattrs'), attrs)

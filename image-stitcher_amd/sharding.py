@@ -17,6 +17,39 @@ from .placement import Shifts
 SHIFT_ROW = 8   # valid, h_dy, h_dx, v_dy, v_dx, rev_dy, rev_dx, rev_odd  (rev_* = 0 and valid&2 unset without S-Pattern)
 
 
+def rank_and_world(group=None) -> Tuple[int, int]:
+    """(rank, world_size) of the default process group, (0, 1) when not distributed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def collective_device(stitcher):
+    """Where collective tensors must live: the GPU for nccl (RCCL), the host for gloo."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        return stitcher.device
+    return None
+
+
+def broadcast_object(obj, src: int = 0):
+    """Small host objects every rank must agree on (the timestamped output folder, an estimated
+    flatfield): rank ``src``'s value everywhere.  Identity when not distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def barrier() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def block_cyclic(n_items: int, rank: int, world: int) -> List[int]:
     """Indices of the work items rank ``rank`` owns: i with i % world == rank."""
     if not (0 <= rank < world):

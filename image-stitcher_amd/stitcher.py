@@ -27,8 +27,9 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import native, placement, registration
+from . import native, placement, registration, sharding
 from .omezarr import write_ome_zarr
+from .ometiff import write_ome_tiff
 from .placement import Shifts
 from .stitcher_parameters import StitchingParameters
 from .tiffio import read_image
@@ -257,6 +258,13 @@ class Stitcher:
         rev = getattr(self, 'h_shift_rev', None) if self.scan_pattern == 'S-Pattern' else None
         return Shifts(tuple(self.h_shift), tuple(self.v_shift), None if rev is None else tuple(rev),
                       int(getattr(self, 'h_shift_rev_odd', 0)))
+
+    def _apply_shifts(self, s: Optional[Shifts]) -> None:
+        if s is None:
+            return
+        self.h_shift, self.v_shift = tuple(s.h_shift), tuple(s.v_shift)
+        if s.h_shift_rev is not None:
+            self.h_shift_rev, self.h_shift_rev_odd = tuple(s.h_shift_rev), s.h_shift_rev_odd
 
     def calculate_output_dimensions(self, timepoint, region):
         """(width_pixels, height_pixels); also sets x/y_positions and num_pyramid_levels
@@ -545,9 +553,20 @@ class Stitcher:
         return output_path
 
     def save_region_aics(self, timepoint, region, stitched_region):
-        """OME-TIFF output (stitcher.py:691-769) needs aicsimageio, which is not part of the hot
-        path and not available offline."""
-        raise NotImplementedError("'.ome.tiff' output is outside the hot-path scope (SURVEY.md 8f); use '.ome.zarr'")
+        """OME-TIFF (or, for a '.ome.zarr' format, OME-Zarr) output (stitcher.py:691-769) through the
+        package-free writers: same path template, channel names / colours, physical pixel sizes."""
+        if self.output_format.endswith('.zarr'):
+            return self.save_region_ome_zarr(timepoint, region, stitched_region)
+        if hasattr(stitched_region, 'cpu'):
+            stitched_region = stitched_region.cpu().numpy()
+        output_path = os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched{self.output_format}")
+        os.makedirs(os.path.dirname(output_path), exist_ok=True)
+        print(f"Writing OME-TIFF to: {output_path}")
+        dz_um = float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
+        write_ome_tiff(output_path, np.asarray(stitched_region), pixel_size_um=self.pixel_size_um, dz_um=dz_um,
+                       channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
+                       name=f"{region}_t{timepoint}")
+        return output_path
 
     # --------------------------------------------------------------------- run
     def run(self):
@@ -558,33 +577,43 @@ class Stitcher:
         self.extract_acquisition_parameters()
         self.get_pixel_size()
         self.parse_acquisition_metadata()
+        # One process per GPU (torchrun): rank 0 registers, the shift table is all-gathered (RCCL
+        # over xGMI with the nccl backend), and the (timepoint, region) units are dealt to the ranks
+        # block-cyclically -- they are independent, so no image data is ever exchanged.
+        rank, world = sharding.rank_and_world()
+        self.output_folder = sharding.broadcast_object(self.output_folder)   # the name embeds datetime.now()
         os.makedirs(self.output_folder, exist_ok=True)
         if self.apply_flatfield:
-            print("Calculating flatfields...")
-            self.getting_flatfields.emit()
-            self.get_flatfields(progress_callback=self.update_progress.emit)
-            print("Time to calculate flatfields:", time.time() - stime)
+            if rank == 0:
+                print("Calculating flatfields...")
+                self.getting_flatfields.emit()
+                self.get_flatfields(progress_callback=self.update_progress.emit)
+                print("Time to calculate flatfields:", time.time() - stime)
+            self.flatfields = sharding.broadcast_object(self.flatfields)   # the estimate samples tiles at random
         if self.use_registration:
-            print(f"\nCalculating shifts on region {self.regions[0]}...")
-            self.calculate_shifts(self.timepoints[0], self.regions[0])
+            if rank == 0:
+                print(f"\nCalculating shifts on region {self.regions[0]}...")
+                self.calculate_shifts(self.timepoints[0], self.regions[0])
+            if world > 1:
+                row = sharding.shifts_to_row(self._shifts() if rank == 0 else None)
+                table = sharding.all_gather_shift_table(row[None], device=sharding.collective_device(self))
+                self._apply_shifts(sharding.first_valid(table))
+        units = [(int(t), region) for t in self.timepoints for region in self.regions]
         output_path = None
-        for timepoint in self.timepoints:
-            timepoint = int(timepoint)
-            ttime = time.time()
-            print(f"\nProcessing timepoint {timepoint}")
+        for i in sharding.block_cyclic(len(units), rank, world):
+            timepoint, region = units[i]
+            rtime = time.time()
+            print(f"\nProcessing timepoint {timepoint}, region {region}" + (f" (rank {rank}/{world})" if world > 1 else ""))
             os.makedirs(os.path.join(self.output_folder, f"{timepoint}_stitched"), exist_ok=True)
-            for region in self.regions:
-                rtime = time.time()
-                print(f"Processing region {region}...")
-                self.starting_stitching.emit()
-                stitched_region = self.stitch_region(timepoint, region, progress_callback=self.update_progress.emit)
-                self.starting_saving.emit(False)
-                if self.output_format.endswith('.zarr'):
-                    output_path = self.save_region_ome_zarr(timepoint, region, stitched_region)
-                else:
-                    output_path = self.save_region_aics(timepoint, region, stitched_region)
-                print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
-            print(f"Completed timepoint {timepoint}: {time.time() - ttime}")
+            self.starting_stitching.emit()
+            stitched_region = self.stitch_region(timepoint, region, progress_callback=self.update_progress.emit)
+            self.starting_saving.emit(False)
+            if self.output_format.endswith('.zarr'):
+                output_path = self.save_region_ome_zarr(timepoint, region, stitched_region)
+            else:
+                output_path = self.save_region_aics(timepoint, region, stitched_region)
+            print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
+        sharding.barrier()
         self.starting_saving.emit(True)
         if self.merge_timepoints or self.merge_hcs_regions:
             print("Note: merging timepoints / HCS regions is an output-format step outside the hot-path scope; "

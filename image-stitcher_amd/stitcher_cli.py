@@ -46,11 +46,33 @@ def create_params(args: argparse.Namespace) -> StitchingParameters:
         'merge_hcs_regions': args.merge_hcs_regions, 'dynamic_registration': args.dynamic_registration})
 
 
+def init_distributed():
+    """Under torchrun (WORLD_SIZE > 1): one process per GPU, RCCL process group."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('SQ_DIST_BACKEND', 'nccl')
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(device)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if not dist.is_initialized():
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return device
+
+
 def main(argv=None):
     args = parse_args(argv)
     try:
+        device = init_distributed()
         params = create_params(args)
-        stitcher = Stitcher(params, fusion_mode=args.fusion_mode,
+        stitcher = Stitcher(params, device=device, fusion_mode=args.fusion_mode,
                             normalization=None if args.normalization == 'none' else 'phase')
         print("Starting stitching with parameters:")
         for k, v in params.to_dict().items():

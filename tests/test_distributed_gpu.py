@@ -1,0 +1,42 @@
+"""The product's multi-process path on the GPU box: two ranks (gloo rendezvous, both on cuda:0 --
+one GPU is all the box has; on an 8-GPU node the same code runs one rank per GPU over RCCL)
+run ``Stitcher.run()`` on a multi-region, multi-timepoint acquisition.  Rank 0 registers, the shift
+table is all-gathered, the (t, region) units are split, and every store equals the reference's
+canvas."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import load_case, spec_of
+from image_stitcher_amd import omezarr, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, root):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SQ_DIST_BACKEND='gloo')
+    from image_stitcher_amd import stitcher_cli
+    stitcher_cli.main(['-i', root, '-r', '--normalization', 'none'])
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_ranks_split_regions_and_agree_on_shifts(tmp_path):
+    import torch.multiprocessing as mp
+    info, arrays = load_case('reg_multi')          # regions A1, B2 x timepoints 0, 1
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, root), nprocs=2, join=True)
+    outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
+    assert len(outs) == 1, "both ranks must write into the folder rank 0 named"
+    for key in info['canvases']:
+        t, region = key[1:].split('_', 1)
+        store = os.path.join(tmp_path, outs[0], f'{t}_stitched', f'{region}_stitched.ome.zarr')
+        np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])

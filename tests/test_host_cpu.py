@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import REGION_CASES, load_case, spec_of
-from image_stitcher_amd import omezarr, placement, synth, tiffio
+from image_stitcher_amd import ometiff, omezarr, placement, synth, tiffio
 from image_stitcher_amd.stitcher_parameters import StitchingParameters
 from image_stitcher_amd import stitcher_cli
 from oracle import stitch_oracle as O
@@ -69,6 +69,27 @@ def test_omezarr_roundtrip(tmp_path):
     assert [a['name'] for a in ms['axes']] == ['t', 'c', 'z', 'y', 'x']
     assert ms['datasets'][2]['coordinateTransformations'][0]['scale'] == [1, 1, 1.5, 2.0, 2.0]
     assert [c['label'] for c in attrs['omero']['channels']] == ['a 405', 'b 488']
+
+
+def test_ometiff_roundtrip(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 65536, (2, 3, 2, 37, 53)).astype(np.uint16)
+    path = ometiff.write_ome_tiff(str(tmp_path / 'r.ome.tiff'), img, pixel_size_um=0.5, dz_um=1.5,
+                                  channel_names=['a 405', 'b <488>', 'c'], channel_colors=[0xFF, 0xFF00, 0xFF0000], name='R0_t0')
+    planes, xml = ometiff.read_ome_tiff(path)
+    assert len(planes) == 12
+    np.testing.assert_array_equal(np.stack(planes).reshape(img.shape), img)       # IFD order = T, C, Z (XYZCT)
+    import xml.etree.ElementTree as ET
+    root = ET.fromstring(xml)
+    ns = {'o': 'http://www.openmicroscopy.org/Schemas/OME/2016-06'}
+    px = root.find('o:Image/o:Pixels', ns)
+    assert (px.get('SizeT'), px.get('SizeC'), px.get('SizeZ'), px.get('SizeY'), px.get('SizeX')) == ('2', '3', '2', '37', '53')
+    assert px.get('DimensionOrder') == 'XYZCT' and px.get('Type') == 'uint16' and px.get('PhysicalSizeZ') == '1.5'
+    assert [c.get('Name') for c in px.findall('o:Channel', ns)] == ['a 405', 'b <488>', 'c']
+    assert len(px.findall('o:TiffData', ns)) == 12
+    # the plain TIFF reader of this repo opens the first plane of the BigTIFF? no -- BigTIFF is not baseline
+    with pytest.raises(ValueError):
+        ometiff.write_ome_tiff(str(tmp_path / 'bad.ome.tiff'), img[0], pixel_size_um=1.0)
 
 
 @pytest.mark.parametrize('name', REGION_CASES)
