@@ -267,12 +267,22 @@ __device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
 #define SQ_DEPTH_F64 1
 #endif
 
+#ifndef SQ_WAVES_F32
+#define SQ_WAVES_F32 1
+#endif
+#ifndef SQ_WAVES_F64
+#define SQ_WAVES_F64 1
+#endif
 template <typename T, int FLAT>
-__global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
+__global__ __launch_bounds__(256, (FLAT == 1 ? SQ_WAVES_F32 : (FLAT == 2 ? SQ_WAVES_F64 : 1)))
+void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
                                                               const int64_t n_work) {
     constexpr int VEC = Pix<T>::N;
     constexpr int FSZ = FLAT == 2 ? 8 : 4;
-    constexpr int RB = BLOCK_ROWS / 4;
+#ifndef SQ_RB_FLAT
+#define SQ_RB_FLAT (BLOCK_ROWS / 4)
+#endif
+    constexpr int RB = FLAT ? SQ_RB_FLAT : BLOCK_ROWS / 4;   // rows a wave pipelines together
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;   // vectors per lane per row (+1: alignment phase)
     constexpr int NSTEP = RB * SLOTS;
     constexpr int WANT = FLAT == 0 ? SQ_DEPTH_PLAIN : (FLAT == 1 ? SQ_DEPTH_F32 : SQ_DEPTH_F64);
@@ -306,10 +316,11 @@ __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P,
                 row_zero<T>(canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
         } else {
             const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+            for (int rb = wave; rb < rows; rb += 4 * RB) {
             Row<T> J[RB];
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                const int r = wave + 4 * j;
+                const int r = rb + 4 * j;
                 J[j].n = r < rows ? n : 0;
                 J[j].drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
                 J[j].srow = tile + (int64_t)(it.b + r) * P.tile_pitch + it.c;
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(256) void fuse_overwrite_kernel(const FuseParams P,
                     const int d = s - DEPTH;
                     slot_store<T, FLAT>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
                 }
+            }
             }
         }
         if (!more) break;
