@@ -74,6 +74,7 @@ struct FuseParams {
     int64_t canvas_plane_stride;
     int32_t n_tiles, tile_h, tile_w, tile_pitch;
     int32_t canvas_pitch;
+    const uint32_t *flat_class;   // per plane: 0 = every gain is a normal float (fast divide allowed)
 };
 
 template <typename T>
@@ -96,6 +97,35 @@ __device__ __forceinline__ T flat_f32(T v, float g) {
     q = fminf(fmaxf(q, 0.0f), hi);
     return (T)q;
 }
+// Fast exact flatfield divide for THIS operand class: numerator an integer in [0, 65535], gain any
+// NORMAL float32 (either sign).  Markstein's scheme -- reciprocal refined by one Newton step on
+// v_rcp_f32, one quotient, one exact-residual correction -- gives the correctly rounded quotient
+// here because a 16-bit numerator keeps n/g at least 2^-41 (relative) away from every rounding
+// boundary, far more than the 2^-46 the uncorrected error can reach.  The first quotient is clamped
+// to +-2^20 so that gains small enough to overflow it (where the answer clips to the dtype maximum
+// anyway) cannot turn the correction into inf - inf.  None of this is taken on faith:
+// sq_selftest_flat_divide compares the final clipped integers with the IEEE path for ALL 2^23
+// mantissas x 65536 numerators in every one of the 254 normal binades (tests/test_fuse_gpu.py).
+// Zeros, denormals, infinities and NaNs among a plane's gains are found by a pre-pass
+// (flat_classify_kernel) and send that plane through the generic IEEE sequence instead.
+// Saves the two v_div_scale, v_div_fmas, v_div_fixup and the second refinement (11 -> 7 VALU slots).
+__device__ __forceinline__ float div_u16_normal(float n, float g) {
+    float r = __builtin_amdgcn_rcpf(g);
+    const float e = fmaf(-g, r, 1.0f);
+    r = fmaf(e, r, r);
+    float q = __builtin_amdgcn_fmed3f(n * r, -0x1p20f, 0x1p20f);
+    const float rem = fmaf(-g, q, n);
+    return fmaf(rem, r, q);
+}
+
+template <typename T>
+__device__ __forceinline__ T flat_f32_fast(T v, float g) {
+    float q = div_u16_normal((float)v, g);
+    const float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
+    q = fminf(fmaxf(q, 0.0f), hi);
+    return (T)q;
+}
+
 template <typename T>
 __device__ __forceinline__ T flat_f64(T v, double g) {
     double q = __ddiv_rn((double)v, g);
@@ -212,18 +242,26 @@ __device__ __forceinline__ void slot_load(Slot<T, FLAT> &S, const Row<T> &J, int
 }
 
 // non-temporal stores: the canvas is written once and never read back by this kernel
-template <typename T, int FLAT>
+template <typename T, int FLAT, bool FAST>
 __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, int lane, int k) {
     constexpr int VEC = Pix<T>::N;
     const int v = lane + 64 * k;
     if (v >= J.v_first && v < J.v_end) {
         u32x4 px = S.px;
         if (FLAT == 1 && J.frow) {
+            if (FAST) {   // every gain of this plane is a normal float (flag from the pre-pass)
 #pragma unroll
-            for (int q = 0; q < VEC / 4; ++q)
+                for (int q = 0; q < VEC / 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+                    for (int e = 0; e < 4; ++e)
+                        Pix<T>::set(px, 4 * q + e, flat_f32_fast<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+            }
         } else if (FLAT == 2 && J.frow) {
 #pragma unroll
             for (int q = 0; q < VEC / 2; ++q)
@@ -235,7 +273,7 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
     }
     if (k == 0 && J.edge_p >= 0) {
         T t = S.edge;
-        if (FLAT == 1 && J.frow) t = flat_f32<T>(t, S.eg32);
+        if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T>(t, S.eg32) : flat_f32<T>(t, S.eg32);
         if (FLAT == 2 && J.frow) t = flat_f64<T>(t, S.eg64);
         stg_s<T>(J.drow + J.edge_p, t);
     }
@@ -266,6 +304,21 @@ __device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
 #ifndef SQ_DEPTH_F64
 #define SQ_DEPTH_F64 1
 #endif
+
+// the software pipeline over the (row, slot) steps of RB rows (see the comment above Row)
+template <typename T, int FLAT, bool FAST, int RB, int SLOTS, int DEPTH>
+__device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
+    constexpr int NSTEP = RB * SLOTS;
+    Slot<T, FLAT> buf[DEPTH + 1];
+#pragma unroll
+    for (int s = 0; s < NSTEP + DEPTH; ++s) {
+        if (s < NSTEP) slot_load<T, FLAT>(buf[s % (DEPTH + 1)], J[s / SLOTS], lane, s % SLOTS);
+        if (s >= DEPTH) {
+            const int d = s - DEPTH;
+            slot_store<T, FLAT, FAST>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
+        }
+    }
+}
 
 #ifndef SQ_WAVES_F32
 #define SQ_WAVES_F32 1
@@ -316,6 +369,7 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
                 row_zero<T>(canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
         } else {
             const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+            const bool fast = FLAT == 1 && P.flat_class && P.flat_class[plane] == 0;
             for (int rb = wave; rb < rows; rb += 4 * RB) {
             Row<T> J[RB];
 #pragma unroll
@@ -327,15 +381,8 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items,
                 J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
                 row_setup<T>(J[j], lane);
             }
-            Slot<T, FLAT> buf[DEPTH + 1];
-#pragma unroll
-            for (int s = 0; s < NSTEP + DEPTH; ++s) {
-                if (s < NSTEP) slot_load<T, FLAT>(buf[s % (DEPTH + 1)], J[s / SLOTS], lane, s % SLOTS);
-                if (s >= DEPTH) {
-                    const int d = s - DEPTH;
-                    slot_store<T, FLAT>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
-                }
-            }
+            if (fast) pipeline_rows<T, FLAT, true, RB, SLOTS, DEPTH>(J, lane);
+            else pipeline_rows<T, FLAT, false, RB, SLOTS, DEPTH>(J, lane);
             }
         }
         if (!more) break;
@@ -504,7 +551,53 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
     return SQ_OK;
 }
 
+// pre-pass: does a plane's flatfield hold anything but normal floats?
+__global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *flat_ptrs, int64_t n, uint32_t *cls) {
+    const int plane = blockIdx.y;
+    const float *f = static_cast<const float *>(flat_ptrs[plane]);
+    if (!f) return;
+    bool odd = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        odd |= !__builtin_amdgcn_classf(ldg_s<float>(f + i), 0x108);   // 0x008 -normal | 0x100 +normal
+    if (__builtin_amdgcn_ballot_w64(odd) && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], 1u);
+}
+
+// exhaustive check of the fast divide against the IEEE path: final clipped integers, one binade of
+// the gain per blockIdx.y, every mantissa, every uint16 numerator
+__global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int negative, unsigned long long *bad) {
+    const uint32_t mant = blockIdx.x * 256u + threadIdx.x;   // 2^23 mantissas
+    const int exponent = exponent0 + (int)blockIdx.y;
+    const uint32_t bits = ((uint32_t)(exponent + 127) << 23) | mant | (negative ? 0x80000000u : 0u);
+    const float g = __uint_as_float(bits);
+    unsigned long long local = 0;
+    for (int v = 0; v < 65536; ++v)
+        local += flat_f32<uint16_t>((uint16_t)v, g) != flat_f32_fast<uint16_t>((uint16_t)v, g);
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
+}
+
 }  // namespace
+
+extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
+                                       void *stream) {
+    if (!mismatches_dev || exponent < -126 || n_binades < 1 || exponent + n_binades - 1 > 127)
+        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide: binades [%d, %d] outside the normal range [-126, 127]",
+                    exponent, exponent + n_binades - 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_divide_kernel, dim3(1u << 15, n_binades), dim3(256), 0, s, exponent, negative,
+                           reinterpret_cast<unsigned long long *>(mismatches_dev));
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_flat_divide: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+extern "C" int64_t sq_fuse_scratch_bytes(int32_t n_planes) {
+    if (n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_scratch_bytes: n_planes %d", n_planes);
+    return ((int64_t)n_planes * 4 + 15) & ~int64_t(15);
+}
 
 extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (!a || !a->plan || !a->table_dev || !a->canvas_dev)
@@ -551,8 +644,21 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.tile_w = a->tile_w;
     P.tile_pitch = a->tile_pitch;
     P.canvas_pitch = a->canvas_pitch;
+    P.flat_class = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
+    if (flat == 1 && a->scratch_dev && a->mode == SQ_FUSE_OVERWRITE && a->n_planes > 0) {
+        // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
+        if (a->scratch_bytes < sq_fuse_scratch_bytes(a->n_planes))
+            return fail(SQ_ERR_WORKSPACE, "sq_fuse_planes: scratch %lld < %lld bytes", (long long)a->scratch_bytes,
+                        (long long)sq_fuse_scratch_bytes(a->n_planes));
+        if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 4) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 4-byte aligned");
+        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)a->n_planes * 4, stream) != hipSuccess)
+            return fail(SQ_ERR_HIP, "sq_fuse_planes: cannot clear the scratch");
+        hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
+                           (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+        P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
+    }
     const bool u16 = a->tile_dtype == SQ_U16;
 
     if (a->mode == SQ_FUSE_OVERWRITE) {

@@ -45,6 +45,7 @@ class _FuseArgs(C.Structure):
         ('canvas_dev', C.c_void_p), ('canvas_plane_stride', C.c_int64),
         ('canvas_h', C.c_int32), ('canvas_w', C.c_int32), ('canvas_pitch', C.c_int32),
         ('canvas_dtype', C.c_int32), ('n_planes', C.c_int32), ('mode', C.c_int32),
+        ('scratch_dev', C.c_void_p), ('scratch_bytes', C.c_int64),
     ]
 
 
@@ -73,6 +74,8 @@ EXPORTS = {
                                  C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_register_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
+    'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
     'sq_synth_tiles': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -255,6 +258,11 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
         fp = pointer_table(flats, canvas.device)
         keep.append(fp)
         a.flat_ptrs_dev = fp.data_ptr()
+        nbytes = L.sq_fuse_scratch_bytes(n_planes)
+        scratch = torch.empty(max(16, int(nbytes)), dtype=torch.uint8, device=canvas.device)
+        keep.append(scratch)
+        a.scratch_dev = scratch.data_ptr()
+        a.scratch_bytes = scratch.numel()
     a.canvas_dev = canvas.data_ptr()
     a.canvas_plane_stride = hc * wc
     a.canvas_h, a.canvas_w, a.canvas_pitch = hc, wc, wc
@@ -354,6 +362,15 @@ def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_
     """register_pairs_async + fetch: returns a RESULT_DTYPE host array (synchronises)."""
     return register_pairs_async(tiles, minmax, pairs, n0, n1, upsample_factor, normalization, stream,
                                 tile_ptrs, shape, np_dtype).fetch()
+
+
+def selftest_flat_divide(exponent: int, n_binades: int, negative: bool, device) -> int:
+    """Mismatches between the fast and the IEEE flatfield divide over whole binades of gains (tests)."""
+    import torch
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(lib().sq_selftest_flat_divide(int(exponent), int(n_binades), int(bool(negative)), out.data_ptr(),
+                                         _stream_ptr()), 'sq_selftest_flat_divide')
+    return int(out.item())
 
 
 def synth_tiles(desc: np.ndarray, tile_h: int, tile_w: int, noise_amp: int, np_dtype, device, out=None, stream=None):

@@ -106,7 +106,13 @@ typedef struct sq_fuse_args {
     int32_t canvas_dtype; /* overwrite: == tile_dtype; feather: tile_dtype or SQ_F32       */
     int32_t n_planes;
     int32_t mode; /* must match the plan                                               */
+    /* optional scratch, sq_fuse_scratch_bytes(n_planes) bytes: lets the call classify each plane's   */
+    /* float32 gains (all normal floats?) and use the shortened exact divide; NULL = generic divide   */
+    void *scratch_dev;
+    int64_t scratch_bytes;
 } sq_fuse_args;
+
+int64_t sq_fuse_scratch_bytes(int32_t n_planes);
 
 /* Fuse n_planes planes.  Every canvas voxel is written exactly once (uncovered voxels = 0,
  * the reference starts from da.zeros, stitcher.py:362); no atomics; deterministic. */
@@ -167,6 +173,14 @@ typedef struct sq_register_args {
 /* Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
+
+/* Self-test (tests only): the fusion kernel divides uint16 pixels by float32 gains with a shortened
+ * sequence that is exact for normal gains.  This compares its final clipped integers with the IEEE
+ * path for ALL 2^23 gain mantissas x all 65536 numerators in n_binades consecutive binades starting
+ * at 2^exponent (normal range: -126..127), either sign, and leaves the number of differing results
+ * in *mismatches_dev (must be 0). */
+int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic tiles on the device (bench / tests only): the generator of

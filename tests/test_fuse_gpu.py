@@ -169,3 +169,37 @@ def test_fuse_argument_errors_are_reported():
         native.fuse_planes(plan, tiles, torch.zeros((1, 16, 24), dtype=torch.uint16, device=dev))
     with pytest.raises(ValueError, match='elements'):
         native.fuse_planes(plan, tiles[:, :, :4], torch.zeros((1, 16, 16), dtype=torch.uint16, device=dev))
+
+
+def test_fast_flatfield_divide_is_exact_exhaustively():
+    """The shortened float32 divide of the fusion kernel gives the same clipped integer as the IEEE
+    path for every normal gain (all 2^23 mantissas of all 254 binades) x every uint16 numerator --
+    1.4e14 pairs -- and for negative gains in a spread of binades.  Planes whose flatfield holds a
+    zero, denormal, infinity or NaN never reach it (pre-pass), see the next test."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    for e0 in range(-126, 128, 32):
+        n = min(32, 128 - e0)
+        assert native.selftest_flat_divide(e0, n, False, dev) == 0, (e0, n)
+    for e0 in (-126, -100, -20, -1, 0, 15, 16, 100, 127):
+        assert native.selftest_flat_divide(e0, 1, True, dev) == 0, e0
+    with pytest.raises(native.NativeError, match='outside'):
+        native.selftest_flat_divide(120, 10, False, dev)
+
+
+def test_flatfield_fast_and_slow_paths_mix_in_one_vector():
+    """Gains that leave the fast range (0, denormal, huge, inf, NaN, negative) sit next to ordinary
+    ones inside the same 8-pixel vectors."""
+    rng = np.random.default_rng(77)
+    th, tw = 32, 64
+    tiles = rng.integers(0, 65536, size=(1, 1, th, tw)).astype(np.uint16)
+    flat = (0.5 + rng.random((th, tw))).astype(np.float32)
+    odd = np.array([0.0, -0.0, 1e-40, 1e-38, 3e38, np.inf, -np.inf, np.nan, -1.5, 1e-31, 1e31, 2.0 ** -100, 2.0 ** 100,
+                    2.0 ** -101, 1e-34, 5e-35], dtype=np.float32)
+    for i, g in enumerate(odd):
+        flat[(3 * i) % th, (11 * i + 5) % tw] = g
+        flat[(5 * i + 1) % th, (7 * i) % tw] = g
+    tiles[0, 0, 0, :8] = [0, 1, 65535, 2, 3, 4, 5, 6]
+    rects = np.array([(0, 0, th, tw, 0, 0)])
+    got, _ = run_fuse(rects, tiles, th, tw, flats_np=[flat])
+    np.testing.assert_array_equal(got[0], O.fuse_plane_overwrite(list(tiles[0]), rects, th, tw, flat))
