@@ -45,7 +45,7 @@ struct TableHeader {
     int64_t n_spans, n_refs, n_items;
     int64_t off_spans, off_refs, off_items;  // byte offsets from the table start
     int64_t covered_voxels;
-    int64_t reserved;   // items per XCD lane when the item list is lane-interleaved (else 0)
+    int64_t reserved;
 };
 static_assert(sizeof(TableHeader) == 96, "TableHeader layout");
 

@@ -62,8 +62,6 @@ __device__ __forceinline__ void stg_s(void *p, S v) {
     *(SQ_GLOBAL S *)p = v;
 }
 
-constexpr int QUEUE_STRIDE = 32;   // uint32 words between work counters = one 128-byte line each
-
 struct FuseParams {
     const Span *spans;
     const Ref *refs;
@@ -77,9 +75,6 @@ struct FuseParams {
     int32_t n_tiles, tile_h, tile_w, tile_pitch;
     int32_t canvas_pitch;
     const uint32_t *flat_class;   // per plane: 0 = every gain is a normal float (fast divide allowed)
-    uint32_t *queue;              // 9 work counters (8 XCD lanes + tail), zeroed per launch; NULL = static stride
-    int32_t lane_len, tail_len;   // items per XCD lane / after the lanes, per plane
-    int32_t n_planes;
 };
 
 template <typename T>
@@ -369,119 +364,42 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
     }
 }
 
-// Work distribution.
-//  * static (no scratch given): persistent grid-stride walk, block b takes items b, b + G, ...
-//  * dynamic (scratch given): nine device counters -- one per XCD lane of the item list plus one for
-//    the leftovers.  A workgroup reads the XCD it really runs on (HW_REG_XCC_ID), pulls the next
-//    index of THAT lane with one atomicAdd, and steals from the other lanes / the tail once its own
-//    is drained.  In-flight items of an XCD therefore always form one contiguous window of its lane
-//    (same tile-row block, same flatfield rows, fetched into that XCD's L2 once), however unevenly
-//    workgroups progress: with the static stride, blocks drift apart over a 40 ms launch and the
-//    flatfield re-fetch came back (PMC: 46 GB of 205 GB fetched per launch).
-//    Thread 0 pulls two items ahead: the atomic for item i+2 is issued before item i is processed and
-//    its result is only looked at afterwards, the descriptor of item i+1 is loaded meanwhile, and one
-//    barrier per item hands the index to the other waves through LDS.
-struct WorkRef {
-    int q;         // 0..7 lane, 8 tail, -1 none
-    uint32_t w;
-};
-
+// Work distribution: a persistent grid-stride walk.  Tried and rejected (measured): nine device
+// counters (one per XCD lane of the item list + leftovers) pulled with atomicAdd by workgroups that
+// read the XCD they really run on (HW_REG_XCC_ID).  It pins every XCD to one contiguous window of
+// its lane -- rocprofv3 FETCH_SIZE fell from 57.8e6 KB to 35.8e6 KB per launch, i.e. the flatfield
+// was fetched exactly once -- but the per-item barrier + atomic cost more than the L2 misses it
+// removed (they are served by the Infinity Cache): 3320 vs 3594 GB/s on the same box.
 template <typename T, int FLAT>
 __global__ __launch_bounds__(256, (FLAT == 1 ? SQ_WAVES_F32 : (FLAT == 2 ? SQ_WAVES_F64 : 1)))
 void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
-    if (!P.queue) {
-        // static: the next descriptor and tile pointer are fetched while the current item streams
-        int64_t work = blockIdx.x;
-        if (work >= n_work) return;
-        int plane = (int)(work / n_items);
-        Item it = P.items[work - plane * n_items];
-        const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
-        while (true) {
-            const int64_t nwork = work + gridDim.x;
-            const bool more = nwork < n_work;
-            int nplane = plane;
-            Item nit = it;
-            const T *ntile = nullptr;
-            if (more) {
-                nplane = (int)(nwork / n_items);
-                nit = P.items[nwork - nplane * n_items];
-                ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
-            }
-            process_item<T, FLAT>(P, plane, it, tile, wave, lane);
-            if (!more) break;
-            work = nwork;
-            plane = nplane;
-            it = nit;
-            tile = ntile;
-        }
-        return;
-    }
-
-    // ---- dynamic: per-XCD work queues --------------------------------------------------------
-    __shared__ int s_q[3];
-    __shared__ uint32_t s_w[3];
-    const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // HW_REG_XCC_ID[3:0]
-    const uint32_t lane_total = (uint32_t)P.n_planes * (uint32_t)P.lane_len;
-    const uint32_t tail_total = (uint32_t)P.n_planes * (uint32_t)P.tail_len;
-    int t = 0;   // thread 0: how many queues it has given up on (0 = its own lane ... 8 = tail)
-    auto queue_of = [&](int tt) { return tt < 8 ? ((xcd + tt) & 7) : 8; };
-    auto settle = [&](uint32_t w) -> WorkRef {   // thread 0: make (t, w) valid or move on
-        while (true) {
-            const int q = queue_of(t);
-            if (w < (q < 8 ? lane_total : tail_total)) return {q, w};
-            if (++t > 8) return {-1, 0u};
-            w = atomicAdd(&P.queue[queue_of(t) * QUEUE_STRIDE], 1u);
-        }
-    };
-    auto locate = [&](WorkRef r, int &plane) -> int64_t {   // -> position in the item list
-        if (r.q < 8) {
-            plane = (int)(r.w / (uint32_t)P.lane_len);
-            return (int64_t)(r.w - (uint32_t)plane * (uint32_t)P.lane_len) * 8 + r.q;
-        }
-        plane = (int)(r.w / (uint32_t)P.tail_len);
-        return (int64_t)P.lane_len * 8 + (r.w - (uint32_t)plane * (uint32_t)P.tail_len);
-    };
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 2; ++k) {
-            const WorkRef r = t > 8 ? WorkRef{-1, 0u} : settle(atomicAdd(&P.queue[queue_of(t) * QUEUE_STRIDE], 1u));
-            s_q[k] = r.q;
-            s_w[k] = r.w;
-        }
-    }
-    __syncthreads();
-    WorkRef cur = {__builtin_amdgcn_readfirstlane(s_q[0]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[0])};
-    WorkRef nxt = {__builtin_amdgcn_readfirstlane(s_q[1]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[1])};
-    if (cur.q < 0) return;
-    int plane = 0;
-    Item it = P.items[locate(cur, plane)];
+    // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
+    // pointer are fetched while the current item streams
+    int64_t work = blockIdx.x;
+    if (work >= n_work) return;
+    int plane = (int)(work / n_items);
+    Item it = P.items[work - plane * n_items];
     const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
-    for (int i = 0;; ++i) {
-        uint32_t pending = 0;
-        const bool pull = threadIdx.x == 0 && nxt.q >= 0 && t <= 8;
-        if (pull) pending = atomicAdd(&P.queue[queue_of(t) * QUEUE_STRIDE], 1u);   // for item i+2; consumed after the item
+    while (true) {
+        const int64_t nwork = work + gridDim.x;
+        const bool more = nwork < n_work;
         int nplane = plane;
         Item nit = it;
         const T *ntile = nullptr;
-        if (nxt.q >= 0) {
-            nit = P.items[locate(nxt, nplane)];
+        if (more) {
+            nplane = (int)(nwork / n_items);
+            nit = P.items[nwork - nplane * n_items];
             ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
         }
         process_item<T, FLAT>(P, plane, it, tile, wave, lane);
-        if (nxt.q < 0) break;
-        if (threadIdx.x == 0) {
-            const WorkRef r = pull ? settle(pending) : WorkRef{-1, 0u};
-            s_q[(i + 2) % 3] = r.q;
-            s_w[(i + 2) % 3] = r.w;
-        }
-        __syncthreads();
-        cur = nxt;
+        if (!more) break;
+        work = nwork;
         plane = nplane;
         it = nit;
         tile = ntile;
-        nxt = {__builtin_amdgcn_readfirstlane(s_q[(i + 2) % 3]), (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[(i + 2) % 3])};
     }
 }
 
@@ -686,14 +604,9 @@ extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int3
     return SQ_OK;
 }
 
-// scratch = [n_planes x uint32 gain class][pad to 256][9 work counters, one per 128-byte line]
-// (the counters are hammered by device-scope atomics: nothing that is merely READ may share a line
-// with them, and they must not share lines with each other)
-static int64_t scratch_queue_offset(int32_t n_planes) { return ((int64_t)n_planes * 4 + 255) & ~int64_t(255); }
-
 extern "C" int64_t sq_fuse_scratch_bytes(int32_t n_planes) {
     if (n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_scratch_bytes: n_planes %d", n_planes);
-    return scratch_queue_offset(n_planes) + 9 * QUEUE_STRIDE * 4;
+    return ((int64_t)n_planes * 4 + 15) & ~int64_t(15);   // one uint32 gain class per plane
 }
 
 extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
@@ -744,30 +657,17 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.flat_class = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
-    P.queue = nullptr;
-    P.n_planes = a->n_planes;
-    if (a->scratch_dev && a->mode == SQ_FUSE_OVERWRITE && a->n_planes > 0) {
+    if (flat == 1 && a->scratch_dev && a->mode == SQ_FUSE_OVERWRITE && a->n_planes > 0) {
+        // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
         if (a->scratch_bytes < sq_fuse_scratch_bytes(a->n_planes))
             return fail(SQ_ERR_WORKSPACE, "sq_fuse_planes: scratch %lld < %lld bytes", (long long)a->scratch_bytes,
                         (long long)sq_fuse_scratch_bytes(a->n_planes));
         if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 4) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 4-byte aligned");
-        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)sq_fuse_scratch_bytes(a->n_planes), stream) != hipSuccess)
+        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)a->n_planes * 4, stream) != hipSuccess)
             return fail(SQ_ERR_HIP, "sq_fuse_planes: cannot clear the scratch");
-        if (flat == 1) {
-            // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
-            hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
-                               (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
-            P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
-        }
-        // per-XCD work queues need the XCD-lane layout of the item list (plan built with it) and
-        // counters that cannot overflow
-        const int64_t lane_len = h.reserved, tail_len = h.n_items - 8 * h.reserved;
-        if (flat && lane_len >= 0 && tail_len >= 0 && (lane_len + tail_len) * (int64_t)a->n_planes < (int64_t)1 << 31 &&
-            !getenv("SQ_FUSE_STATIC")) {   // without a flatfield nothing is shared between items: static stride
-            P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + scratch_queue_offset(a->n_planes));
-            P.lane_len = (int32_t)lane_len;
-            P.tail_len = (int32_t)tail_len;
-        }
+        hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
+                           (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+        P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
     }
     const bool u16 = a->tile_dtype == SQ_U16;
 

@@ -276,7 +276,6 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     hd.off_refs = hd.off_spans + hd.n_spans * (int64_t)sizeof(Span);
     hd.off_items = hd.off_refs + hd.n_refs * (int64_t)sizeof(Ref);
     hd.covered_voxels = covered;
-    hd.reserved = 0;   // items per XCD lane (list positions [0, 8*reserved) are lane-interleaved); set below
     const int64_t total = hd.off_items + hd.n_items * (int64_t)sizeof(Item);
     plan->table.resize((size_t)total);
     char *p = &plan->table[0];
@@ -304,10 +303,6 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         for (int x = 0; x < NX; ++x) {
             tail_at[x] = tail;
             tail += lane_len[x] - common;
-        }
-        if (order_mode == 2) {
-            hd.reserved = common;
-            std::memcpy(p, &hd, sizeof hd);
         }
         std::vector<int64_t> seen(nblk, 0);
         for_each_item([&](const Item &it) {
