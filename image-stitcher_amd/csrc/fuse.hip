@@ -97,33 +97,49 @@ __device__ __forceinline__ T flat_f32(T v, float g) {
     q = fminf(fmaxf(q, 0.0f), hi);
     return (T)q;
 }
-// Fast exact flatfield divide for THIS operand class: numerator an integer in [0, 65535], gain any
-// NORMAL float32 (either sign).  Markstein's scheme -- reciprocal refined by one Newton step on
-// v_rcp_f32, one quotient, one exact-residual correction -- gives the correctly rounded quotient
-// here because a 16-bit numerator keeps n/g at least 2^-41 (relative) away from every rounding
-// boundary, far more than the 2^-46 the uncorrected error can reach.  The first quotient is clamped
-// to +-2^20 so that gains small enough to overflow it (where the answer clips to the dtype maximum
-// anyway) cannot turn the correction into inf - inf.  None of this is taken on faith:
-// sq_selftest_flat_divide compares the final clipped integers with the IEEE path for ALL 2^23
-// mantissas x 65536 numerators in every one of the 254 normal binades (tests/test_fuse_gpu.py).
-// Zeros, denormals, infinities and NaNs among a plane's gains are found by a pre-pass
-// (flat_classify_kernel) and send that plane through the generic IEEE sequence instead.
-// Saves the two v_div_scale, v_div_fmas, v_div_fixup and the second refinement (11 -> 7 VALU slots).
+// Fast exact flatfield divide for THIS operand class: numerator an integer in [0, 65535], gain a
+// float32 with 2^-100 <= |g| < 2^128 (either sign).  Markstein's scheme -- reciprocal refined by one
+// Newton step on v_rcp_f32, one quotient, one exact-residual correction -- gives the correctly
+// rounded quotient here because a 16-bit numerator keeps n/g at least 2^-41 (relative) away from
+// every rounding boundary, far more than the 2^-46 the uncorrected error can reach.  Below 2^-112
+// the first quotient would overflow and the correction turn into inf - inf; the guard leaves a wide
+// margin.  None of this is taken on faith: sq_selftest_flat_divide compares the final clipped
+// integers with the IEEE path for ALL 2^23 mantissas x 65536 numerators in every binade of the
+// range (tests/test_fuse_gpu.py).  Zeros, denormals, tiny gains, infinities and NaNs among a
+// plane's gains are found by a pre-pass (flat_classify_kernel) and send that plane through the
+// generic IEEE sequence instead.
+// Saves the two v_div_scale, v_div_fmas, v_div_fixup and the second refinement (11 -> 6 VALU slots).
 __device__ __forceinline__ float div_u16_normal(float n, float g) {
     float r = __builtin_amdgcn_rcpf(g);
     const float e = fmaf(-g, r, 1.0f);
     r = fmaf(e, r, r);
-    float q = __builtin_amdgcn_fmed3f(n * r, -0x1p20f, 0x1p20f);
+    const float q = n * r;
     const float rem = fmaf(-g, q, n);
     return fmaf(rem, r, q);
+}
+constexpr int FAST_MIN_EXP = -100;   // fast divide allowed for 2^FAST_MIN_EXP <= |g| < 2^128
+
+// float -> uint32 the way the hardware does it: negative and NaN -> 0, too large -> 0xFFFFFFFF.
+// (C++'s (uint32_t)f is undefined outside the range, so say the instruction.)
+__device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 
 template <typename T>
 __device__ __forceinline__ T flat_f32_fast(T v, float g) {
-    float q = div_u16_normal((float)v, g);
-    const float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
-    q = fminf(fmaxf(q, 0.0f), hi);
-    return (T)q;
+    // clip(q, 0, max) then truncate == saturating conversions: NaN never occurs on this path
+    const uint32_t k = cvt_u32_sat(div_u16_normal((float)v, g));
+    return (T)min(k, sizeof(T) == 1 ? 255u : 65535u);
+}
+// two pixels of one 32-bit word at once: v_cvt_pk_u16_u32 saturates to 65535 and packs
+__device__ __forceinline__ uint32_t flat_f32_fast_pair(uint32_t word, float g_lo, float g_hi) {
+    const uint32_t a = cvt_u32_sat(div_u16_normal((float)(word & 0xFFFFu), g_lo));
+    const uint32_t b = cvt_u32_sat(div_u16_normal((float)(word >> 16), g_hi));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
 
 template <typename T>
@@ -249,7 +265,13 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
     if (v >= J.v_first && v < J.v_end) {
         u32x4 px = S.px;
         if (FLAT == 1 && J.frow) {
-            if (FAST) {   // every gain of this plane is a normal float (flag from the pre-pass)
+            if (FAST && sizeof(T) == 2) {   // every gain of this plane is inside the fast range (pre-pass flag)
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    px[2 * q] = flat_f32_fast_pair(px[2 * q], S.g32[q][0], S.g32[q][1]);
+                    px[2 * q + 1] = flat_f32_fast_pair(px[2 * q + 1], S.g32[q][2], S.g32[q][3]);
+                }
+            } else if (FAST) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q)
 #pragma unroll
@@ -561,14 +583,17 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
     return SQ_OK;
 }
 
-// pre-pass: does a plane's flatfield hold anything but normal floats?
+// pre-pass: does a plane's flatfield hold anything outside the fast divide's range?
 __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *flat_ptrs, int64_t n, uint32_t *cls) {
     const int plane = blockIdx.y;
     const float *f = static_cast<const float *>(flat_ptrs[plane]);
     if (!f) return;
     bool odd = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        odd |= !__builtin_amdgcn_classf(ldg_s<float>(f + i), 0x108);   // 0x008 -normal | 0x100 +normal
+    {
+        const float g = fabsf(ldg_s<float>(f + i));
+        odd |= !(g >= __builtin_ldexpf(1.0f, FAST_MIN_EXP) && g < __builtin_inff());   // NaN fails both
+    }
     if (__builtin_amdgcn_ballot_w64(odd) && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], 1u);
 }
 
@@ -581,7 +606,13 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int
     const float g = __uint_as_float(bits);
     unsigned long long local = 0;
     for (int v = 0; v < 65536; ++v)
-        local += flat_f32<uint16_t>((uint16_t)v, g) != flat_f32_fast<uint16_t>((uint16_t)v, g);
+    {
+        const uint32_t want = flat_f32<uint16_t>((uint16_t)v, g);   // the IEEE path
+        const uint32_t pair = flat_f32_fast_pair((uint32_t)v | ((uint32_t)v << 16), g, g);
+        local += want != flat_f32_fast<uint16_t>((uint16_t)v, g);
+        local += want != (pair & 0xFFFFu);
+        local += want != (pair >> 16);
+    }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
 }
@@ -590,9 +621,9 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int
 
 extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
                                        void *stream) {
-    if (!mismatches_dev || exponent < -126 || n_binades < 1 || exponent + n_binades - 1 > 127)
-        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide: binades [%d, %d] outside the normal range [-126, 127]",
-                    exponent, exponent + n_binades - 1);
+    if (!mismatches_dev || exponent < FAST_MIN_EXP || n_binades < 1 || exponent + n_binades - 1 > 127)
+        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide: binades [%d, %d] outside the fast path's range [%d, 127]",
+                    exponent, exponent + n_binades - 1, FAST_MIN_EXP);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s);
     if (e == hipSuccess) {
