@@ -234,7 +234,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, max_planes=10):
+def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, max_planes=16):
     """The oracle (a numpy port of the reference path) on a bounded sample of the same workload:
     registration of the two centre pairs once (stitcher.py:1244-1246), then overwrite fusion of
     up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work."""

@@ -204,3 +204,33 @@ def test_flatfield_fast_and_slow_paths_mix_in_one_vector():
     rects = np.array([(0, 0, th, tw, 0, 0)])
     got, _ = run_fuse(rects, tiles, th, tw, flats_np=[flat])
     np.testing.assert_array_equal(got[0], O.fuse_plane_overwrite(list(tiles[0]), rects, th, tw, flat))
+
+
+def test_rects_clipped_by_the_canvas_and_empty_rects():
+    """Rectangles that stick out of the canvas are clipped like the reference's python slices
+    (stitcher.py:590-594); rectangles that start outside it or have no area write nothing."""
+    rng = np.random.default_rng(5)
+    th, tw, ch, cw = 40, 56, 90, 100
+    rects = np.array([(0, 0, th, tw, 70, 10),      # bottom rows clipped
+                      (3, 5, 30, 50, 20, 80),      # right columns clipped
+                      (0, 0, th, tw, 60, 60),      # both
+                      (0, 0, th, tw, 90, 0),       # starts below the canvas
+                      (0, 0, 0, 10, 5, 5),         # empty
+                      (10, 10, 5, 0, 5, 5)])       # empty
+    tiles = rng.integers(1, 65536, size=(1, len(rects), th, tw)).astype(np.uint16)
+    got, plan = run_fuse(rects, tiles, ch, cw)
+    want = O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw)
+    np.testing.assert_array_equal(got[0], want)
+    assert plan.covered_voxels == int((want != 0).sum())
+
+
+@pytest.mark.parametrize('out_dtype', ['uint8', 'float32'])
+def test_feather_uint8_tiles(out_dtype):
+    rng = np.random.default_rng(8)
+    th, tw, ch, cw = 33, 47, 120, 131
+    rects = np.array([(0, 0, th, tw, int(y), int(x)) for y, x in zip(rng.integers(0, ch - 20, 12), rng.integers(0, cw - 20, 12))])
+    tiles = rng.integers(0, 256, size=(2, 12, th, tw)).astype(np.uint8)
+    flat = (0.7 + 0.6 * rng.random((th, tw))).astype(np.float64)
+    got, _ = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=[flat, None], out_dtype=out_dtype, n_planes=2)
+    for p, f in enumerate((flat, None)):
+        np.testing.assert_array_equal(got[p], O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, f, out_dtype=np.dtype(out_dtype).type))

@@ -156,3 +156,18 @@ def test_config2_crop_shape_1024x256_and_all_pairs_batch():
         want = O.phase_cross_correlation(a, b, 10, 'phase')[0]
         np.testing.assert_array_equal(vs[k], want)
         assert registration.vertical_shift_from(vs[k], v0) == (-244, -2)
+
+
+def test_long_non_power_of_two_lines():
+    """3000 x 3000 sensors give 1500-long crops (direct-DFT path, O(n^2)): same shifts as the oracle."""
+    rng = np.random.default_rng(4)
+    for n0, n1 in ((1500, 48), (48, 1500), (750, 100)):
+        big = synth.scene_patch(77, 0, 0, n0 + 64, n1 + 64)
+        dy, dx = 7, -5
+        ref = big[32:32 + n0, 32:32 + n1].astype(np.uint16)
+        mov = (big[32 - dy:32 - dy + n0, 32 - dx:32 - dx + n1] + synth.noise_patch(3, n0, n1, 200)).astype(np.uint16)
+        for norm in (None, 'phase'):
+            want = O.phase_cross_correlation(ref, mov, 10, norm)[0]
+            got = registration.phase_cross_correlation(ref, mov, upsample_factor=10, normalization=norm)[0]
+            np.testing.assert_array_equal(got, want, err_msg=f'{n0}x{n1} {norm}')
+            assert want.tolist() == [-dy, -dx]
