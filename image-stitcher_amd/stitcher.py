@@ -493,7 +493,17 @@ class Stitcher:
             r = np.array([it[2] for it in items], dtype=np.int64).reshape(-1, 6)
             groups.setdefault(r.tobytes(), []).append(p)
             rect_of[r.tobytes()] = r
+        # Ingest pipeline: file decode (host threads) -> pinned staging -> async H2D -> fusion, two slots
+        # deep, so the files of batch k+1 are read while batch k is copied and fused.  A batch is a
+        # few planes: bounded by free HBM, by host memory and by what is sensible to pin.
         free_bytes = torch.cuda.mem_get_info(self.device)[0]
+        try:
+            import psutil
+            host_free = psutil.virtual_memory().available
+        except Exception:   # pragma: no cover
+            host_free = 8 << 30
+        budget = max(1, min(int(free_bytes * 0.2), int(host_free * 0.1), 4 << 30))
+        tdtype = native.torch_dtype_of(self.dtype)
         processed = 0
         pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
         try:
@@ -502,13 +512,19 @@ class Stitcher:
                 n = len(rects)
                 plan = self._plan_for(rects, th, tw, hc, wc, mode)
                 per_plane = n * th * tw * np.dtype(self.dtype).itemsize
-                batch = max(1, min(len(plist), int(free_bytes * 0.5) // max(1, per_plane)))
-                for b0 in range(0, len(plist), batch):
-                    chunk = plist[b0:b0 + batch]
-                    contiguous = all(chunk[i] + 1 == chunk[i + 1] for i in range(len(chunk) - 1))
-                    host = np.empty((len(chunk), n, th, tw), dtype=self.dtype)
+                batch = max(1, min(len(plist), budget // max(1, per_plane)))
+                chunks = [plist[b0:b0 + batch] for b0 in range(0, len(plist), batch)]
+                n_slots = min(2, len(chunks))
+                staging = [torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)]
+                on_dev = [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)]
+                done = [None] * n_slots
+                for k, chunk in enumerate(chunks):
+                    slot = k % n_slots
+                    if done[slot] is not None:
+                        done[slot].synchronize()      # the slot's previous copy and fusion have finished
+                    host = staging[slot].numpy()
 
-                    def load(job):
+                    def load(job, host=host):
                         pi, ti, (info, rgb, _) = job
                         img = read_image(info['filepath'])
                         if rgb >= 0:
@@ -524,14 +540,19 @@ class Stitcher:
                         processed += 1
                         if progress_callback:
                             progress_callback(processed - 1, total_tiles)
-                    tiles = torch.from_numpy(host).to(self.device)
+                    m = len(chunk)
+                    tiles = on_dev[slot][:m]
+                    tiles.copy_(staging[slot][:m], non_blocking=True)
                     flats = [flats_dev.get(p // self.num_z) for p in chunk] if self.apply_flatfield else None
+                    contiguous = all(chunk[i] + 1 == chunk[i + 1] for i in range(m - 1))
                     if contiguous:
-                        native.fuse_planes(plan, tiles, flat_canvas[chunk[0]:chunk[0] + len(chunk)], flats)
+                        native.fuse_planes(plan, tiles, flat_canvas[chunk[0]:chunk[0] + m], flats)
                     else:
                         for pi, p in enumerate(chunk):
                             native.fuse_planes(plan, tiles[pi:pi + 1], flat_canvas[p:p + 1],
                                                None if flats is None else flats[pi:pi + 1])
+                    done[slot] = torch.cuda.Event()
+                    done[slot].record()
         finally:
             pool.shutdown(wait=True)
         torch.cuda.synchronize(self.device)
