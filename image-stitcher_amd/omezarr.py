@@ -22,7 +22,9 @@ def _write_json(path: str, obj) -> None:
         json.dump(obj, fh, indent=1)
 
 
-def write_array(path: str, data: np.ndarray, chunks: Sequence[int], level: int = 1) -> None:
+def write_array(path: str, data: np.ndarray, chunks: Sequence[int], level: int = 1, workers: Optional[int] = None) -> None:
+    """One zarr v2 array; chunks are compressed and written by a thread pool (zlib releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(path, exist_ok=True)
     chunks = tuple(int(min(c, s)) if s else int(c) for c, s in zip(chunks, data.shape))
     _write_json(os.path.join(path, '.zarray'), {
@@ -30,22 +32,32 @@ def write_array(path: str, data: np.ndarray, chunks: Sequence[int], level: int =
         'dtype': data.dtype.newbyteorder('<').str if data.dtype.itemsize > 1 else data.dtype.str,
         'compressor': {'id': 'zlib', 'level': level}, 'fill_value': 0, 'order': 'C', 'filters': None,
         'dimension_separator': '/'})
-    grid = [range(0, s, c) for s, c in zip(data.shape, chunks)]
-    for t in grid[0]:
-        for c in grid[1]:
-            for z in grid[2]:
-                for y in grid[3]:
-                    for x in grid[4]:
-                        block = data[t:t + chunks[0], c:c + chunks[1], z:z + chunks[2], y:y + chunks[3], x:x + chunks[4]]
-                        if not block.any():
-                            continue   # fill_value
-                        full = np.zeros(chunks, dtype=data.dtype)
-                        full[tuple(slice(0, s) for s in block.shape)] = block
-                        idx = (t // chunks[0], c // chunks[1], z // chunks[2], y // chunks[3], x // chunks[4])
-                        cdir = os.path.join(path, *map(str, idx[:-1]))
-                        os.makedirs(cdir, exist_ok=True)
-                        with open(os.path.join(cdir, str(idx[-1])), 'wb') as fh:
-                            fh.write(zlib.compress(np.ascontiguousarray(full).tobytes(), level))
+
+    def emit(origin):
+        sl = tuple(slice(o, o + c) for o, c in zip(origin, chunks))
+        block = data[sl]
+        if not block.any():
+            return   # fill_value
+        if block.shape != chunks:
+            full = np.zeros(chunks, dtype=data.dtype)
+            full[tuple(slice(0, s) for s in block.shape)] = block
+            block = full
+        idx = tuple(o // c for o, c in zip(origin, chunks))
+        cdir = os.path.join(path, *map(str, idx[:-1]))
+        os.makedirs(cdir, exist_ok=True)
+        with open(os.path.join(cdir, str(idx[-1])), 'wb') as fh:
+            fh.write(zlib.compress(np.ascontiguousarray(block).tobytes(), level))
+
+    origins = [(t, c, z, y, x) for t in range(0, data.shape[0], chunks[0]) for c in range(0, data.shape[1], chunks[1])
+               for z in range(0, data.shape[2], chunks[2]) for y in range(0, data.shape[3], chunks[3])
+               for x in range(0, data.shape[4], chunks[4])]
+    n = workers if workers is not None else min(32, os.cpu_count() or 4)
+    if n <= 1 or len(origins) < 4:
+        for o in origins:
+            emit(o)
+    else:
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            list(pool.map(emit, origins))
 
 
 def read_array(path: str) -> np.ndarray:
