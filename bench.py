@@ -226,15 +226,21 @@ def main():
     if rank == 0 and os.environ.get('SQ_BENCH_BREAKDOWN'):
         n = args.steps + args.warmup
         print('[bench] host ms per step: ' + ', '.join(f'{k} {v / n * 1e3:.2f}' for k, v in lap.items()), file=sys.stderr)
+    # accuracy side of the metric (BASELINE.json: shift RMSE <= 0.5 px, fused max-rel-err <= 1e-5)
+    sh = state['shifts']
+    err = np.array([sh.h_shift[0] - truth.h_shift[0], sh.h_shift[1] - truth.h_shift[1],
+                    sh.v_shift[0] - truth.v_shift[0], sh.v_shift[1] - truth.v_shift[1]], dtype=np.float64)
+    out['parity'] = {'shift_rmse_px': float(np.sqrt((err ** 2).mean())), 'shift_reference': 'planted drift'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth)
+        out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, canvas)
+        out['parity'].update(check)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, max_planes=16):
+def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, canvas, max_planes=16):
     """The oracle (a numpy port of the reference path) on a bounded sample of the same workload:
     registration of the two centre pairs once (stitcher.py:1244-1246), then overwrite fusion of
     up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work."""
@@ -251,14 +257,22 @@ def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, tru
     assert (tuple(h), tuple(v)) == (truth.h_shift, truth.v_shift)
     rects = placement.grid_rects(g, g, TILE, TILE, placement.Shifts(tuple(h), tuple(v)), order=order_rc)
     voxels = 0
+    dt_check = 0.0
+    mismatched = 0
     for p in range(n):
         plane = O.fuse_plane_overwrite([host[p, i] for i in order], rects, hc, wc, flats[p])
         voxels += plane.size
+        tc = time.perf_counter()   # the comparison with the GPU canvas is not part of the CPU timing
+        mismatched += int(np.count_nonzero(canvas[p].cpu().numpy() != plane))
+        dt_check += time.perf_counter() - tc
         del plane
-    dt = time.perf_counter() - t0
-    return {'value': round(voxels / dt / 1e6, 1), 'unit': 'Mvoxel/s', 'cores': 1, 'kind': 'port',
+    dt = time.perf_counter() - t0 - dt_check
+    base = {'value': round(voxels / dt / 1e6, 1), 'unit': 'Mvoxel/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n} (c,z) planes of the workload ({g}x{g} tiles -> {hc}x{wc} canvas each): registration of '
                       f'the 2 centre pairs once + fusion, numpy oracle, {dt:.1f} s, 1 of {os.cpu_count()} host cores used'}
+    check = {'fused_max_rel_err': 0.0 if mismatched == 0 else None, 'fused_mismatched_voxels': mismatched,
+             'fused_checked': f'{n} of the timed launch\'s canvas planes compared voxel by voxel with the oracle'}
+    return base, check
 
 
 if __name__ == '__main__':
