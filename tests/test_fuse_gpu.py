@@ -234,3 +234,26 @@ def test_feather_uint8_tiles(out_dtype):
     got, _ = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=[flat, None], out_dtype=out_dtype, n_planes=2)
     for p, f in enumerate((flat, None)):
         np.testing.assert_array_equal(got[p], O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, f, out_dtype=np.dtype(out_dtype).type))
+
+
+@pytest.mark.parametrize('dtype', ['uint16', 'uint8'])
+def test_fast_and_generic_divide_agree_on_real_planes(dtype):
+    """Same tiles, same gains, once through the fast divide (every gain in range) and once through
+    the generic IEEE sequence (one gain zeroed makes the pre-pass flag the plane): identical output
+    wherever the zeroed gain is not involved, and both equal to the oracle."""
+    rng = np.random.default_rng(123)
+    th, tw, ch, cw, n = 72, 136, 300, 517, 14
+    rects = random_rects(rng, n, th, tw, ch - 30, cw - 30)
+    tiles = rng.integers(0, np.iinfo(dtype).max + 1, size=(1, n, th, tw)).astype(dtype)
+    gains = np.exp(rng.normal(0.0, 1.5, size=(th, tw))).astype(np.float32)       # wide spread, all normal
+    gains[5, 7], gains[9, 1], gains[40, 100] = 2.0 ** -99, 3.0e37, -0.75         # still inside the fast range
+    fast, _ = run_fuse(rects, tiles, ch, cw, flats_np=[gains])
+    np.testing.assert_array_equal(fast[0], O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw, gains))
+    flagged = gains.copy()
+    flagged[0, 0] = 0.0
+    slow, _ = run_fuse(rects, tiles, ch, cw, flats_np=[flagged])
+    want_slow = O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw, flagged)
+    np.testing.assert_array_equal(slow[0], want_slow)
+    same = want_slow == O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw, gains)
+    np.testing.assert_array_equal(fast[0][same], slow[0][same])
+    assert (~same).sum() <= n      # at most one voxel per tile differs (pixel (0, 0) where it is visible)
