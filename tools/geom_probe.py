@@ -30,6 +30,8 @@ def run(name, crop_l, crop_t, step_x, step_y, pad_w=0, pad_h=0, off=0):
     print(f'{name:58s} canvas {hc}x{wc} cov {cov/(hc*wc):.3f} spans {plan.n_spans:5d}: {ms:7.3f} ms {alg/ms/1e6:7.1f} GB/s', flush=True)
     del canvas
 run('full tiles, abutting', 0, 0, T, T)
+run('crop 256 horizontally only (w 1536 = 3 full wave-instrs)', 256, 0, T - 512, T)
+run('crop 192 horizontally only (w 1664 = 3.25 wave-instrs)', 192, 0, T - 384, T)
 run('crop 128 (w 1792), abutting, aligned', 128, 128, T - 256, T - 256)
 run('crop 120 (w 1808), abutting, aligned', 120, 120, T - 240, T - 240)
 run('crop 122 (w 1804), abutting (dst phase varies)', 122, 122, T - 244, T - 244)
