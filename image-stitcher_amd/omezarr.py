@@ -22,46 +22,8 @@ def _write_json(path: str, obj) -> None:
         json.dump(obj, fh, indent=1)
 
 
-def write_array(path: str, data: np.ndarray, chunks: Sequence[int], level: int = 1, workers: Optional[int] = None) -> None:
-    """One zarr v2 array; chunks are compressed and written by a thread pool (zlib releases the GIL)."""
-    from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(path, exist_ok=True)
-    chunks = tuple(int(min(c, s)) if s else int(c) for c, s in zip(chunks, data.shape))
-    _write_json(os.path.join(path, '.zarray'), {
-        'zarr_format': 2, 'shape': list(data.shape), 'chunks': list(chunks),
-        'dtype': data.dtype.newbyteorder('<').str if data.dtype.itemsize > 1 else data.dtype.str,
-        'compressor': {'id': 'zlib', 'level': level}, 'fill_value': 0, 'order': 'C', 'filters': None,
-        'dimension_separator': '/'})
-
-    def emit(origin):
-        sl = tuple(slice(o, o + c) for o, c in zip(origin, chunks))
-        block = data[sl]
-        if not block.any():
-            return   # fill_value
-        if block.shape != chunks:
-            full = np.zeros(chunks, dtype=data.dtype)
-            full[tuple(slice(0, s) for s in block.shape)] = block
-            block = full
-        idx = tuple(o // c for o, c in zip(origin, chunks))
-        cdir = os.path.join(path, *map(str, idx[:-1]))
-        os.makedirs(cdir, exist_ok=True)
-        with open(os.path.join(cdir, str(idx[-1])), 'wb') as fh:
-            fh.write(zlib.compress(np.ascontiguousarray(block).tobytes(), level))
-
-    origins = [(t, c, z, y, x) for t in range(0, data.shape[0], chunks[0]) for c in range(0, data.shape[1], chunks[1])
-               for z in range(0, data.shape[2], chunks[2]) for y in range(0, data.shape[3], chunks[3])
-               for x in range(0, data.shape[4], chunks[4])]
-    n = workers if workers is not None else min(32, os.cpu_count() or 4)
-    if n <= 1 or len(origins) < 4:
-        for o in origins:
-            emit(o)
-    else:
-        with ThreadPoolExecutor(max_workers=n) as pool:
-            list(pool.map(emit, origins))
-
-
 def read_array(path: str) -> np.ndarray:
-    """Inverse of write_array (used by tests to check the store round-trips)."""
+    """One array of a store back into memory (used by tests to check the store round-trips)."""
     with open(os.path.join(path, '.zarray')) as fh:
         meta = json.load(fh)
     shape, chunks, dt = meta['shape'], meta['chunks'], np.dtype(meta['dtype'])
@@ -77,25 +39,44 @@ def read_array(path: str) -> np.ndarray:
     return out
 
 
-def write_ome_zarr(path: str, image: np.ndarray, *, pixel_size_um: float, dz_um: float = 1.0,
-                   channel_names: Sequence[str] = (), channel_colors: Sequence[int] = (),
-                   num_levels: int = 1, chunks=(1, 1, 1, 512, 512), name: str = 'stitched') -> str:
-    """Write a (T, C, Z, Y, X) array as a multiscale OME-Zarr image."""
-    if image.ndim != 5:
-        raise ValueError(f"expected a 5-D TCZYX array, got {image.shape}")
+def level_shapes(shape: Sequence[int], num_levels: int) -> List[tuple]:
+    """TCZYX shapes of the pyramid levels: level l+1 is level l decimated by two in y and x."""
+    out = [tuple(int(v) for v in shape)]
+    for _ in range(1, max(1, num_levels)):
+        t, c, z, y, x = out[-1]
+        if y < 2 or x < 2:
+            break
+        out.append((t, c, z, (y + 1) // 2, (x + 1) // 2))
+    return out
+
+
+def _zarray_meta(shape, chunks, dtype, level=1):
+    dtype = np.dtype(dtype)
+    chunks = tuple(int(min(c, s)) if s else int(c) for c, s in zip(chunks, shape))
+    return chunks, {
+        'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks),
+        'dtype': dtype.newbyteorder('<').str if dtype.itemsize > 1 else dtype.str,
+        'compressor': {'id': 'zlib', 'level': level}, 'fill_value': 0, 'order': 'C', 'filters': None,
+        'dimension_separator': '/'}
+
+
+def create_store(path: str, shape: Sequence[int], dtype, *, pixel_size_um: float, dz_um: float = 1.0,
+                 channel_names: Sequence[str] = (), channel_colors: Sequence[int] = (), num_levels: int = 1,
+                 chunks=(1, 1, 1, 512, 512), name: str = 'stitched') -> List[tuple]:
+    """Group + array metadata of a multiscale OME-Zarr image, no chunks yet.  Returns the level
+    shapes.  Chunks are then added plane by plane (``write_planes``), by any number of processes."""
     os.makedirs(path, exist_ok=True)
     _write_json(os.path.join(path, '.zgroup'), {'zarr_format': 2})
+    shapes = level_shapes(shape, num_levels)
     datasets = []
-    level = image
-    for lv in range(max(1, num_levels)):
-        write_array(os.path.join(path, str(lv)), level, chunks)
-        s = 2 ** lv
+    for lv, shp in enumerate(shapes):
+        os.makedirs(os.path.join(path, str(lv)), exist_ok=True)
+        _write_json(os.path.join(path, str(lv), '.zarray'), _zarray_meta(shp, chunks, dtype)[1])
+        sc = 2 ** lv
         datasets.append({'path': str(lv), 'coordinateTransformations': [
-            {'type': 'scale', 'scale': [1, 1, dz_um, pixel_size_um * s, pixel_size_um * s]}]})
-        if level.shape[-1] < 2 or level.shape[-2] < 2:
-            break
-        level = level[..., ::2, ::2]
-    info = np.iinfo(image.dtype) if np.issubdtype(image.dtype, np.integer) else None
+            {'type': 'scale', 'scale': [1, 1, dz_um, pixel_size_um * sc, pixel_size_um * sc]}]})
+    dt = np.dtype(dtype)
+    info = np.iinfo(dt) if np.issubdtype(dt, np.integer) else None
     attrs = {
         'multiscales': [{
             'version': '0.4', 'name': name,
@@ -111,4 +92,62 @@ def write_ome_zarr(path: str, image: np.ndarray, *, pixel_size_um: float, dz_um:
             for i, n in enumerate(channel_names)]},
     }
     _write_json(os.path.join(path, '.zattrs'), attrs)
+    return shapes
+
+
+def write_planes(path: str, planes: np.ndarray, coords: Sequence[tuple], num_levels: int = 1,
+                 chunks=(1, 1, 1, 512, 512), level: int = 1, workers: Optional[int] = None) -> None:
+    """Write the chunks of whole (t, c, z) planes (``planes[i]`` is the 2-D plane at ``coords[i]``) into
+    every pyramid level of a store made by ``create_store``.  Chunks never span planes (chunk shape
+    (1,1,1,cy,cx)), so different processes can write different planes of one store concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    if tuple(chunks[:3]) != (1, 1, 1):
+        raise ValueError("plane-wise writing needs chunks of shape (1, 1, 1, cy, cx)")
+    jobs = []
+    for i, (t, c, z) in enumerate(coords):
+        lvl = planes[i]
+        for lv in range(max(1, num_levels)):
+            cy, cx = min(chunks[3], lvl.shape[0]), min(chunks[4], lvl.shape[1])
+            for y in range(0, lvl.shape[0], cy):
+                for x in range(0, lvl.shape[1], cx):
+                    jobs.append((lv, t, c, z, y // cy, x // cx, lvl, y, x, cy, cx))
+            if lvl.shape[0] < 2 or lvl.shape[1] < 2:
+                break
+            lvl = lvl[::2, ::2]
+
+    def emit(job):
+        lv, t, c, z, iy, ix, lvl, y, x, cy, cx = job
+        block = lvl[y:y + cy, x:x + cx]
+        if not block.any():
+            return
+        if block.shape != (cy, cx):
+            full = np.zeros((cy, cx), dtype=lvl.dtype)
+            full[:block.shape[0], :block.shape[1]] = block
+            block = full
+        cdir = os.path.join(path, str(lv), str(t), str(c), str(z), str(iy))
+        os.makedirs(cdir, exist_ok=True)
+        with open(os.path.join(cdir, str(ix)), 'wb') as fh:
+            fh.write(zlib.compress(np.ascontiguousarray(block).tobytes(), level))
+
+    n = workers if workers is not None else min(32, os.cpu_count() or 4)
+    if n <= 1 or len(jobs) < 4:
+        for j in jobs:
+            emit(j)
+    else:
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            list(pool.map(emit, jobs))
+
+
+def write_ome_zarr(path: str, image: np.ndarray, *, pixel_size_um: float, dz_um: float = 1.0,
+                   channel_names: Sequence[str] = (), channel_colors: Sequence[int] = (),
+                   num_levels: int = 1, chunks=(1, 1, 1, 512, 512), name: str = 'stitched') -> str:
+    """Write a (T, C, Z, Y, X) array as a multiscale OME-Zarr image."""
+    if image.ndim != 5:
+        raise ValueError(f"expected a 5-D TCZYX array, got {image.shape}")
+    shapes = create_store(path, image.shape, image.dtype, pixel_size_um=pixel_size_um, dz_um=dz_um,
+                          channel_names=channel_names, channel_colors=channel_colors, num_levels=num_levels,
+                          chunks=chunks, name=name)
+    t_, c_, z_ = image.shape[:3]
+    coords = [(t, c, z) for t in range(t_) for c in range(c_) for z in range(z_)]
+    write_planes(path, image.reshape((-1,) + image.shape[3:]), coords, num_levels=len(shapes), chunks=chunks)
     return path

@@ -28,6 +28,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import native, placement, registration, sharding
+from . import omezarr
 from .omezarr import write_ome_zarr
 from .ometiff import write_ome_tiff
 from .placement import Shifts
@@ -450,11 +451,28 @@ class Stitcher:
     def stitch_region(self, timepoint, region, progress_callback=None, device_output: bool = False):
         """Fuse one (timepoint, region) -> 5-D TCZYX array of the input dtype
         (stitcher.py:639-689).  Returns numpy (host) unless ``device_output``."""
+        planes, _ = self.stitch_planes(timepoint, region, None, progress_callback)
+        canvas = planes.view(1, self.num_c, self.num_z, planes.shape[-2], planes.shape[-1])
+        return canvas if device_output else canvas.cpu().numpy()
+
+    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None):
+        """Fuse the (channel, z) planes ``only_planes`` (plane = channel * num_z + z; None = all) of one
+        (timepoint, region) -> (device tensor [n, Hc, Wc], sorted plane ids).  Planes are independent,
+        which is what lets several GPUs share one region."""
         import torch
         start_time = time.time()
         region_data = self.get_region_data(int(timepoint), region)
-        canvas = self.init_output(timepoint, region)
-        hc, wc = int(canvas.shape[3]), int(canvas.shape[4])
+        width, height = self.calculate_output_dimensions(timepoint, region)
+        plane_ids = sorted(set(int(p) for p in only_planes)) if only_planes is not None \
+            else list(range(self.num_c * self.num_z))
+        if plane_ids and (plane_ids[0] < 0 or plane_ids[-1] >= self.num_c * self.num_z):
+            raise ValueError(f"plane ids must lie in [0, {self.num_c * self.num_z})")
+        slot_of = {p: i for i, p in enumerate(plane_ids)}
+        print(f"region {region} timepoint {timepoint} output array dimensions: "
+              f"{(1, self.num_c, self.num_z, height, width)}" + ("" if only_planes is None else f", planes {plane_ids}"))
+        flat_canvas = torch.empty((len(plane_ids), height, width), dtype=native.torch_dtype_of(self.dtype),
+                                  device=self.device)
+        hc, wc = height, width
         th, tw = self.input_height, self.input_width
         total_tiles = len(region_data)
         print(f"Beginning stitching of {total_tiles} tiles for region {region} timepoint {timepoint}")
@@ -465,22 +483,23 @@ class Stitcher:
             _, _, fov, z_level, channel = key
             rect = self._tile_rect(info)
             if channel in self.monochrome_channels:
-                planes.setdefault(self.monochrome_channels.index(channel) * self.num_z + z_level, []).append((info, -1, rect))
+                targets = [(self.monochrome_channels.index(channel) * self.num_z + z_level, -1)]
             else:   # RGB file -> three monochrome channels (stitcher.py:551-556)
                 base = channel.split('_')[0]
-                for i, color in enumerate('RGB'):
-                    ci = self.monochrome_channels.index(f"{base}_{color}")
-                    planes.setdefault(ci * self.num_z + z_level, []).append((info, i, rect))
+                targets = [(self.monochrome_channels.index(f"{base}_{color}") * self.num_z + z_level, i)
+                           for i, color in enumerate('RGB')]
+            for p, rgb in targets:
+                if p in slot_of:
+                    planes.setdefault(p, []).append((info, rgb, rect))
 
         mode = native.SQ_FUSE_OVERWRITE if self.fusion_mode == 'overwrite' else native.SQ_FUSE_FEATHER
-        flat_canvas = canvas.view(self.num_c * self.num_z, hc, wc)
         # planes no file touches still have to come out as zeros
-        empty = [p for p in range(self.num_c * self.num_z) if p not in planes]
+        empty = [p for p in plane_ids if p not in planes]
         if empty:
             zplan = self._plan_for(np.zeros((0, 6)), th, tw, hc, wc, native.SQ_FUSE_OVERWRITE)
             for p in empty:
-                native.fuse_planes(zplan, torch.empty((1, 0, th, tw), dtype=canvas.dtype, device=self.device),
-                                   flat_canvas[p:p + 1])
+                native.fuse_planes(zplan, torch.empty((1, 0, th, tw), dtype=flat_canvas.dtype, device=self.device),
+                                   flat_canvas[slot_of[p]:slot_of[p] + 1])
         flats_dev = {}
         if self.apply_flatfield:
             for ci, ff in self.flatfields.items():
@@ -544,12 +563,12 @@ class Stitcher:
                     tiles = on_dev[slot][:m]
                     tiles.copy_(staging[slot][:m], non_blocking=True)
                     flats = [flats_dev.get(p // self.num_z) for p in chunk] if self.apply_flatfield else None
-                    contiguous = all(chunk[i] + 1 == chunk[i + 1] for i in range(m - 1))
-                    if contiguous:
-                        native.fuse_planes(plan, tiles, flat_canvas[chunk[0]:chunk[0] + m], flats)
+                    slots = [slot_of[p] for p in chunk]
+                    if all(slots[i] + 1 == slots[i + 1] for i in range(m - 1)):
+                        native.fuse_planes(plan, tiles, flat_canvas[slots[0]:slots[0] + m], flats)
                     else:
-                        for pi, p in enumerate(chunk):
-                            native.fuse_planes(plan, tiles[pi:pi + 1], flat_canvas[p:p + 1],
+                        for pi, sl in enumerate(slots):
+                            native.fuse_planes(plan, tiles[pi:pi + 1], flat_canvas[sl:sl + 1],
                                                None if flats is None else flats[pi:pi + 1])
                     done[slot] = torch.cuda.Event()
                     done[slot].record()
@@ -557,7 +576,7 @@ class Stitcher:
             pool.shutdown(wait=True)
         torch.cuda.synchronize(self.device)
         print(f"Time to stitch region {region} timepoint {timepoint}: {time.time() - start_time}")
-        return canvas if device_output else canvas.cpu().numpy()
+        return flat_canvas, plane_ids
 
     # ------------------------------------------------------------------ output
     def save_region_ome_zarr(self, timepoint, region, stitched_region):
@@ -571,6 +590,29 @@ class Stitcher:
                        channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
                        num_levels=self.num_pyramid_levels, chunks=self.chunks or (1, 1, 1, 512, 512),
                        name=f"{region}_t{timepoint}")
+        return output_path
+
+    def _run_region_by_planes(self, timepoint, region, rank, world):
+        """One region shared by all ranks: plane p goes to rank p % world.  Chunks of
+        an OME-Zarr store never span planes, so the ranks write into one store without locking."""
+        mine = sharding.block_cyclic(self.num_c * self.num_z, rank, world)
+        print(f"\nProcessing timepoint {timepoint}, region {region}: planes {mine} (rank {rank}/{world})")
+        self.starting_stitching.emit()
+        planes, ids = self.stitch_planes(timepoint, region, mine, progress_callback=self.update_progress.emit)
+        output_path = os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched.ome.zarr")
+        shape = (1, self.num_c, self.num_z, int(planes.shape[-2]), int(planes.shape[-1]))
+        dz_um = float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
+        chunks = self.chunks or (1, 1, 1, 512, 512)
+        if rank == 0:
+            os.makedirs(os.path.dirname(output_path), exist_ok=True)
+            omezarr.create_store(output_path, shape, self.dtype, pixel_size_um=self.pixel_size_um, dz_um=dz_um,
+                                 channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
+                                 num_levels=self.num_pyramid_levels, chunks=chunks, name=f"{region}_t{timepoint}")
+        sharding.barrier()
+        self.starting_saving.emit(False)
+        coords = [(0, p // self.num_z, p % self.num_z) for p in ids]
+        omezarr.write_planes(output_path, planes.cpu().numpy(), coords, num_levels=self.num_pyramid_levels, chunks=chunks)
+        sharding.barrier()
         return output_path
 
     def save_region_aics(self, timepoint, region, stitched_region):
@@ -621,6 +663,12 @@ class Stitcher:
                 self._apply_shifts(sharding.first_valid(table))
         units = [(int(t), region) for t in self.timepoints for region in self.regions]
         output_path = None
+        if world > 1 and len(units) < world and self.output_format.endswith('.zarr'):
+            # fewer (timepoint, region) units than GPUs: share each region by (channel, z) plane
+            # instead -- every rank fuses its planes and writes their chunks into the common store
+            for timepoint, region in units:
+                output_path = self._run_region_by_planes(timepoint, region, rank, world)
+            units = []
         for i in sharding.block_cyclic(len(units), rank, world):
             timepoint, region = units[i]
             rtime = time.time()

@@ -40,3 +40,30 @@ def test_two_ranks_split_regions_and_agree_on_shifts(tmp_path):
         t, region = key[1:].split('_', 1)
         store = os.path.join(tmp_path, outs[0], f'{t}_stitched', f'{region}_stitched.ome.zarr')
         np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
+
+
+def test_two_ranks_share_one_region_by_planes(tmp_path):
+    """One region, one timepoint, 2 channels x 2 z = 4 planes: with more GPUs than (t, region) units the
+    ranks split the planes and write the chunks of their planes into the same OME-Zarr store."""
+    import torch.multiprocessing as mp
+    info, arrays = load_case('reg_3x4_small')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_planes, args=(2, port, root, info['params']['registration_channel']), nprocs=2, join=True)
+    outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
+    assert len(outs) == 1
+    store = os.path.join(tmp_path, outs[0], '0_stitched', 'R0_stitched.ome.zarr')
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays['t0_R0_canvas'])
+    assert not os.path.exists(os.path.join(store, '1'))      # num_pyramid_levels is 1 for this small canvas
+
+
+def _worker_planes(rank, world, port, root, channel):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SQ_DIST_BACKEND='gloo')
+    from image_stitcher_amd import stitcher_cli
+    stitcher_cli.main(['-i', root, '-r', '--registration-channel', channel, '--registration-z-level', '1',
+                       '--normalization', 'none'])
+    import torch.distributed as dist
+    dist.destroy_process_group()
