@@ -69,11 +69,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    backend = os.environ.get('SQ_DIST_BACKEND', 'nccl')   # 'gloo' only to rehearse N > 1 on a 1-GPU box
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = dev if backend == 'nccl' else None
 
     wl = WORKLOADS[args.workload]
     g, C, Z = wl['grid'], wl['channels'], wl['nz']
@@ -144,7 +150,7 @@ def main():
         shifts = registration.register_grid_center(reg_plane, g, g, xs, ys, spec.pixel_size_um,
                                                    spec.pixel_binning, normalization='phase')
         t = tick('register', t)
-        table = sharding.all_gather_shift_table(sharding.shifts_to_row(shifts)[None], device=dev)
+        table = sharding.all_gather_shift_table(sharding.shifts_to_row(shifts)[None], device=coll_dev)
         mine = sharding.row_to_shifts(table[rank])
         t = tick('allgather', t)
         # host integer geometry + span plan (rebuilt every step: it depends on the shifts)
@@ -180,7 +186,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
