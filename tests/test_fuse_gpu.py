@@ -257,3 +257,48 @@ def test_fast_and_generic_divide_agree_on_real_planes(dtype):
     same = want_slow == O.fuse_plane_overwrite(list(tiles[0]), rects, ch, cw, gains)
     np.testing.assert_array_equal(fast[0][same], slow[0][same])
     assert (~same).sum() <= n      # at most one voxel per tile differs (pixel (0, 0) where it is visible)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_fuzz_geometry_dtype_flat_mode(seed):
+    """Random tile sizes (down to a few pixels: rows shorter than one 16-byte vector), canvas pitches,
+    rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = ['uint16', 'uint8'][seed % 2]
+    th, tw = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+    if seed % 5 == 0:
+        tw = int(rng.integers(2049, 2300))                 # wider than one item: several column blocks
+        th = int(rng.integers(1, 12))
+    ch, cw = int(rng.integers(1, 200)), int(rng.integers(1, 700 if tw < 2049 else 2600))
+    n = int(rng.integers(0, 12))
+    planes = int(rng.integers(1, 4))
+    rects = np.zeros((n, 6), dtype=np.int64)
+    for i in range(n):
+        sy, sx = int(rng.integers(0, th)), int(rng.integers(0, tw))
+        rects[i] = (sy, sx, int(rng.integers(0, th - sy + 1)), int(rng.integers(0, tw - sx + 1)),
+                    int(rng.integers(0, ch + 5)), int(rng.integers(0, cw + 5)))
+    tiles = rng.integers(0, np.iinfo(dtype).max + 1, size=(planes, n, th, tw)).astype(dtype)
+    flat_kind = seed % 3
+    flats = None
+    if flat_kind and n:
+        fd = np.float32 if flat_kind == 1 else np.float64
+        flats = []
+        for p in range(planes):
+            f = np.exp(rng.normal(0, 1, size=(th, tw))).astype(fd)
+            if p % 2:
+                f[rng.integers(0, th), rng.integers(0, tw)] = 0.0     # this plane takes the generic divide
+            flats.append(f if p != 2 else None)
+    feather = seed % 4 == 3 and n > 0
+    if feather:
+        out_dtype = [dtype, 'float32'][seed % 8 == 7]
+        got, _ = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=flats, out_dtype=out_dtype, n_planes=planes)
+        for p in range(planes):
+            want = O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None if flats is None else flats[p],
+                                        out_dtype=np.dtype(out_dtype).type) if n else np.zeros((ch, cw), out_dtype)
+            np.testing.assert_array_equal(got[p], want)
+    else:
+        got, plan = run_fuse(rects, tiles, ch, cw, flats_np=flats, n_planes=planes)
+        for p in range(planes):
+            want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, None if flats is None else flats[p]) if n \
+                else np.zeros((ch, cw), dtype)
+            np.testing.assert_array_equal(got[p], want)
