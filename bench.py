@@ -145,6 +145,8 @@ def main():
         return t
 
     def step(record):
+        if os.environ.get('SQ_BENCH_BREAKDOWN') == '2':
+            torch.cuda.synchronize()      # diagnostic only: lets the host timings below exclude GPU back-pressure
         t = time.perf_counter()
         # registration: centre pairs on the registration plane (stitcher.py:422-498)
         shifts = registration.register_grid_center(reg_plane, g, g, xs, ys, spec.pixel_size_um,

@@ -136,11 +136,34 @@ def coordinate_rect(x_mm: float, y_mm: float, x_min: float, y_min: float, width:
 def grid_rects(n_rows: int, n_cols: int, width: int, height: int, shifts: Shifts,
                order: Optional[Sequence[Tuple[int, int]]] = None, crop: bool = True) -> np.ndarray:
     """[n, 6] rectangles of a full registered grid in write ``order`` (list of (row, col);
-    default row-major)."""
+    default row-major).  Same integers as ``registered_rect`` per tile, computed for all tiles at
+    once in int64 (every product and sum of the reference's formula is an exact integer)."""
     if order is None:
-        order = [(r, c) for r in range(n_rows) for c in range(n_cols)]
-    return np.array([registered_rect(r, c, n_rows, n_cols, width, height, shifts, crop) for r, c in order],
-                    dtype=np.int64).reshape(-1, 6)
+        rows, cols = np.divmod(np.arange(n_rows * n_cols, dtype=np.int64), n_cols)
+    else:
+        rc = np.asarray(order, dtype=np.int64).reshape(-1, 2)
+        rows, cols = rc[:, 0], rc[:, 1]
+    v_shift = shifts.v_shift
+    # per-row horizontal shift (S-Pattern rows use h_shift_rev)
+    hs = np.array([shifts.horizontal_for_row(int(r)) for r in range(n_rows)], dtype=np.int64).reshape(-1, 2)
+    h0, h1 = hs[rows, 0], hs[rows, 1]
+    x_px = cols * (width + h1)
+    y_px = rows * (height + v_shift[0])
+    y_px = y_px + np.where(h0 < 0, (n_cols - 1 - cols) * np.abs(h0), cols * h0)
+    x_px = x_px + ((n_rows - 1 - rows) * abs(v_shift[1]) if v_shift[1] < 0 else rows * v_shift[1])
+    zeros = np.zeros_like(rows)
+    top = bottom = left = right = zeros
+    if crop:
+        # python's floor division on negatives is numpy's too
+        v_crop = np.maximum(0, (-v_shift[0] // 2) - np.abs(h0) // 2)
+        h_crop = np.maximum(0, (-h1 // 2) - abs(v_shift[1]) // 2)
+        top = np.where(rows > 0, v_crop, 0)
+        bottom = np.where(rows < n_rows - 1, v_crop, 0)
+        left = np.where(cols > 0, h_crop, 0)
+        right = np.where(cols < n_cols - 1, h_crop, 0)
+    h = np.maximum(0, height - bottom - top)
+    w = np.maximum(0, width - right - left)
+    return np.stack([top, left, h, w, y_px + top, x_px + left], axis=1).astype(np.int64)
 
 
 def filename_order(fovs: Sequence[int]) -> List[int]:

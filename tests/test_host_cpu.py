@@ -165,3 +165,20 @@ def test_stitcher_refuses_to_run_without_gpu(tmp_path):
     assert st.calculate_output_dimensions(0, 'R0') == O.output_dimensions(xs, ys, 32, 32, spec.pixel_size_um, False)[:2]
     with pytest.raises(RuntimeError, match='no CPU path'):
         st.stitch_region(0, 'R0')
+
+
+def test_grid_rects_vectorised_equals_per_tile_formula():
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        n_rows, n_cols = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        w, h = int(rng.integers(20, 300)), int(rng.integers(20, 300))
+        sh = placement.Shifts((int(rng.integers(-9, 10)), int(rng.integers(-w + 1, 5))),
+                              (int(rng.integers(-h + 1, 5)), int(rng.integers(-9, 10))),
+                              (int(rng.integers(-9, 10)), int(rng.integers(-w + 1, 5))) if rng.random() < 0.5 else None,
+                              int(rng.integers(0, 2)))
+        order = [(int(r), int(c)) for r, c in zip(rng.integers(0, n_rows, 9), rng.integers(0, n_cols, 9))]
+        for crop in (True, False):
+            for od in (None, order):
+                want = np.array([placement.registered_rect(r, c, n_rows, n_cols, w, h, sh, crop)
+                                 for r, c in (od or [(r, c) for r in range(n_rows) for c in range(n_cols)])])
+                np.testing.assert_array_equal(placement.grid_rects(n_rows, n_cols, w, h, sh, od, crop), want.reshape(-1, 6))
