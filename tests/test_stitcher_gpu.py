@@ -110,3 +110,23 @@ def test_feather_mode_runs_and_agrees_with_overwrite_away_from_seams(tmp_path):
     assert canvas.shape == ref.shape
     # tile interiors (covered by one tile only) are identical in both modes
     np.testing.assert_array_equal(canvas[0, 0, 0, 50:80, 50:80], ref[0, 0, 0, 50:80, 50:80])
+
+
+def test_thread_style_start_wait_and_signals(tmp_path):
+    """GUI-style use: start() in the background, signals fire, wait() joins (the reference is a QThread)."""
+    info, arrays = load_case('reg_neg_skew')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    seen = {'progress': 0, 'started': 0, 'saving': [], 'finished': None}
+    st.update_progress.connect(lambda a, b: seen.__setitem__('progress', seen['progress'] + 1))
+    st.starting_stitching.connect(lambda: seen.__setitem__('started', seen['started'] + 1))
+    st.starting_saving.connect(lambda final: seen['saving'].append(final))
+    st.finished_saving.connect(lambda path, dtype: seen.__setitem__('finished', (path, dtype)))
+    st.start()
+    assert st.wait(120000) and not st.isRunning()
+    assert seen['started'] == 1 and seen['progress'] == 9 and seen['saving'] == [False, True]
+    path, dtype = seen['finished']
+    assert path.endswith(os.path.join('0_stitched', 'R0_stitched.ome.zarr')) and dtype == np.uint16
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '0')), arrays['t0_R0_canvas'])
+    assert (list(st.h_shift), list(st.v_shift)) == (info['h_shift'], info['v_shift'])
