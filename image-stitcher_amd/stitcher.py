@@ -140,7 +140,7 @@ class Stitcher:
         actual_mag = ap['tube_lens_mm'] / obj_focal_length_mm
         self.pixel_binning = ap.get('pixel_binning', 1)
         self.pixel_size_um = ap['sensor_pixel_size_um'] / actual_mag
-        print("pixel_size_um:", self.pixel_size_um)
+        print(f"[metadata] pixel size {self.pixel_size_um} um")
 
     @staticmethod
     def _read_coordinates(path: str) -> Dict[tuple, Tuple[float, float, float]]:
@@ -167,11 +167,11 @@ class Stitcher:
         max_z = max_fov = 0
         for timepoint in self.timepoints:
             image_folder = os.path.join(self.input_folder, str(timepoint))
-            print(f"Processing timepoint {timepoint}, image folder: {image_folder}")
+            print(f"[metadata] timepoint {timepoint}: {image_folder}")
             try:
                 coords = self._read_coordinates(os.path.join(image_folder, 'coordinates.csv'))
             except FileNotFoundError:
-                print(f"Warning: coordinates.csv not found for timepoint {timepoint}")
+                print(f"Warning: timepoint {timepoint} has no coordinates.csv, skipped")
                 continue
             files = sorted(f for f in os.listdir(image_folder) if f.endswith(_IMAGE_EXT) and 'focus_camera' not in f)
             for file in files:
@@ -180,7 +180,7 @@ class Stitcher:
                 channel = os.path.splitext(parts[3])[0].replace("_", " ").replace("full ", "full_")
                 pos = coords.get((region, fov, z_level))
                 if pos is None:
-                    print(f"Warning: No coordinates for {file}")
+                    print(f"Warning: {file} has no row in coordinates.csv, skipped")
                     continue
                 key = (int(timepoint), region, fov, z_level, channel)
                 rec = {'filepath': os.path.join(image_folder, file), 'x': pos[0], 'y': pos[1], 'z': pos[2],
@@ -218,10 +218,10 @@ class Stitcher:
                 self.monochrome_channels.append(channel)
         self.num_c = len(self.monochrome_channels)
         self.monochrome_colors = [self.get_channel_color(n) for n in self.monochrome_channels]
-        print(f"Regions: {self.regions}, Channels: {self.channel_names}")
-        print(f"FOV dimensions: {self.input_height}x{self.input_width}")
-        print(f"{self.num_z} Z levels, {self.num_t} Time points")
-        print(f"{self.num_c} Channels: {self.monochrome_channels}")
+        print(f"[metadata] regions {self.regions}; channels {self.channel_names}")
+        print(f"[metadata] tile {self.input_height} x {self.input_width} {np.dtype(self.dtype)}")
+        print(f"[metadata] {self.num_z} z levels, {self.num_t} timepoints, {self.num_fovs_per_region} fovs per region")
+        print(f"[metadata] {self.num_c} output channels: {self.monochrome_channels}")
 
     def get_region_data(self, t, region):
         """(stitcher.py:260-280) -- served from an index built once instead of a full scan."""
@@ -249,9 +249,9 @@ class Stitcher:
                 try:
                     return read_image(value['filepath'])
                 except FileNotFoundError:
-                    print(f"Warning: Tile file not found: {value['filepath']}")
+                    print(f"Warning: cannot open {value['filepath']}")
                     return None
-        print(f"Warning: No matching tile found for region {region}, x={x}, y={y}, channel={channel}, z={z_level}")
+        print(f"Warning: region {region} has no tile at ({x}, {y}) mm for channel {channel}, z {z_level}")
         return None
 
     # ------------------------------------------------------------- geometry
@@ -289,11 +289,10 @@ class Stitcher:
         """(stitcher.py:613-617), host arithmetic (debug / API parity; the device path fuses
         this into the FFT load)."""
         img = np.asarray(img)
-        img_min, img_max = img.min(), img.max()
-        with np.errstate(all='ignore'):
-            img_normalized = (img - img_min) / (img_max - img_min)
-            scale_factor = np.iinfo(self.dtype).max if np.issubdtype(self.dtype, np.integer) else 1
-            return (img_normalized * scale_factor).astype(self.dtype)
+        lo, hi = img.min(), img.max()
+        full_scale = np.iinfo(self.dtype).max if np.issubdtype(self.dtype, np.integer) else 1
+        with np.errstate(all='ignore'):     # hi == lo -> 0/0, exactly like the reference
+            return (((img - lo) / (hi - lo)) * full_scale).astype(self.dtype)
 
     def _register_two(self, img_a, img_b, max_overlap, vertical: bool):
         import torch
@@ -336,7 +335,7 @@ class Stitcher:
         max_x_overlap, max_y_overlap = placement.registration_crop_widths(
             sorted(self.x_positions), sorted(self.y_positions), self.input_width, self.input_height,
             self.pixel_size_um, self.pixel_binning)
-        print("objective calculated - vertical overlap:", max_y_overlap, ", horizontal overlap:", max_x_overlap)
+        print(f"[registration] crop widths from the stage pitch: {max_x_overlap} px horizontal, {max_y_overlap} px vertical")
         cx, cy = (len(x_positions) - 1) // 2, (len(y_positions) - 1) // 2
         center_x, center_y = x_positions[cx], y_positions[cy]
         right_x = bottom_y = None
@@ -347,23 +346,23 @@ class Stitcher:
             if a is not None and b is not None:
                 self.h_shift = self.calculate_horizontal_shift(a, b, max_x_overlap)
             else:
-                print(f"Warning: Missing tiles for horizontal shift calculation in region {region}.")
+                print(f"Warning: region {region}: centre or right tile missing, h_shift stays {self.h_shift}")
         if cy + 1 < len(y_positions):
             bottom_y = y_positions[cy + 1]
             a, b = get(center_x, center_y), get(center_x, bottom_y)
             if a is not None and b is not None:
                 self.v_shift = self.calculate_vertical_shift(a, b, max_y_overlap)
             else:
-                print(f"Warning: Missing tiles for vertical shift calculation in region {region}.")
+                print(f"Warning: region {region}: centre or bottom tile missing, v_shift stays {self.v_shift}")
         if self.scan_pattern == 'S-Pattern' and right_x and bottom_y:
             a, b = get(center_x, bottom_y), get(right_x, bottom_y)
             if a is not None and b is not None:
                 self.h_shift_rev = self.calculate_horizontal_shift(a, b, max_x_overlap)
                 self.h_shift_rev_odd = cy % 2 == 0
-                print(f"Bi-Directional Horizontal Shift - Reverse Horizontal: {self.h_shift_rev}")
+                print(f"[registration] reversed rows: h_shift_rev = {self.h_shift_rev}")
             else:
-                print(f"Warning: Missing tiles for reverse horizontal shift calculation in region {region}.")
-        print(f"Calculated Uni-Directional Shifts - Horizontal: {self.h_shift}, Vertical: {self.v_shift}")
+                print(f"Warning: region {region}: tiles of the reversed row missing, h_shift_rev stays {self.h_shift_rev}")
+        print(f"[registration] h_shift = {self.h_shift}, v_shift = {self.v_shift}")
 
     # -------------------------------------------------------------- flatfield
     def apply_flatfield_correction(self, tile, channel_idx):
@@ -391,7 +390,7 @@ class Stitcher:
             channel_index = self.monochrome_channels.index(channel)
             if channel_index in self.flatfields:
                 continue
-            print(f"Calculating {channel} flatfield...")
+            print(f"[flatfield] estimating {channel}")
             images = []
             for t in self.timepoints:
                 paths = [v['filepath'] for k, v in self.acquisition_metadata.items()

@@ -11,28 +11,32 @@ from .stitcher import Stitcher
 from .stitcher_parameters import StitchingParameters
 
 
-def parse_args(argv=None) -> argparse.Namespace:
-    p = argparse.ArgumentParser(description="Microscopy Image Stitching CLI (MI355X core)")
-    p.add_argument('--input-folder', '-i', required=True, help="Input folder containing images to stitch")
-    p.add_argument('--output-format', '-f', choices=['.ome.zarr', '.ome.tiff'], default='.ome.zarr',
-                   help="Output format for stitched data (default: .ome.zarr)")
-    p.add_argument('--apply-flatfield', '-ff', action='store_true', help="Apply flatfield correction")
-    p.add_argument('--use-registration', '-r', action='store_true', help="Enable image registration")
-    p.add_argument('--registration-channel', help="Channel to use for registration (default: first available channel)")
-    p.add_argument('--registration-z-level', type=int, default=0, help="Z-level to use for registration (default: 0)")
-    p.add_argument('--dynamic-registration', action='store_true', help="Use dynamic registration for improved accuracy")
-    p.add_argument('--scan-pattern', '-s', choices=['Unidirectional', 'S-Pattern'], default='Unidirectional',
-                   help="Microscope scanning pattern (default: Unidirectional)")
-    p.add_argument('--merge-timepoints', '-mt', action='store_true', help="Merge all timepoints into a single dataset")
-    p.add_argument('--merge-hcs-regions', '-mw', action='store_true',
-                   help="Merge all high-content screening regions (wells)")
-    p.add_argument('--params-json', help="Path to a JSON file containing stitching parameters (overrides other arguments)")
+FLAGS = (
+    # (names, kwargs) -- names and semantics as in the reference's argparse set-up (stitcher_cli.py:14-62)
+    (('--input-folder', '-i'), dict(required=True, help="acquisition folder (timepoint sub-folders with tiles and coordinates.csv)")),
+    (('--output-format', '-f'), dict(choices=['.ome.zarr', '.ome.tiff'], default='.ome.zarr', help="container of the stitched output")),
+    (('--apply-flatfield', '-ff'), dict(action='store_true', help="divide every tile by its channel's flatfield")),
+    (('--use-registration', '-r'), dict(action='store_true', help="register the centre tile pairs and place tiles by the measured shifts")),
+    (('--registration-channel',), dict(help="channel the shifts are measured on (first channel when omitted)")),
+    (('--registration-z-level',), dict(type=int, default=0, help="z plane the shifts are measured on")),
+    (('--dynamic-registration',), dict(action='store_true', help="accepted for compatibility (the reference stores and ignores it)")),
+    (('--scan-pattern', '-s'), dict(choices=['Unidirectional', 'S-Pattern'], default='Unidirectional', help="stage scan order")),
+    (('--merge-timepoints', '-mt'), dict(action='store_true', help="request one dataset over all timepoints")),
+    (('--merge-hcs-regions', '-mw'), dict(action='store_true', help="request one plate dataset over all wells")),
+    (('--params-json',), dict(help="JSON file of StitchingParameters; replaces the flags above")),
     # additions of this build
-    p.add_argument('--fusion-mode', choices=['overwrite', 'feather'], default='overwrite',
-                   help="overwrite = the reference's last-writer-wins; feather = distance-weighted blend (extension)")
-    p.add_argument('--normalization', choices=['phase', 'none'], default='phase',
-                   help="cross-power normalisation: phase = scikit-image >= 0.19 default, none = 0.18 behaviour")
-    return p.parse_args(argv)
+    (('--fusion-mode',), dict(choices=['overwrite', 'feather'], default='overwrite',
+                              help="overwrite = the reference's last-writer-wins; feather = distance-weighted blend (extension)")),
+    (('--normalization',), dict(choices=['phase', 'none'], default='phase',
+                                help="cross-power normalisation: phase = scikit-image >= 0.19 default, none = 0.18 behaviour")),
+)
+
+
+def parse_args(argv=None) -> argparse.Namespace:
+    parser = argparse.ArgumentParser(description="Squid tile stitcher, MI355X core")
+    for names, kwargs in FLAGS:
+        parser.add_argument(*names, **kwargs)
+    return parser.parse_args(argv)
 
 
 def create_params(args: argparse.Namespace) -> StitchingParameters:
