@@ -96,7 +96,19 @@ struct RegParams {
     char *ws;
     Layout L;
     int32_t n_pairs, normalization, tc;
+    int32_t n_tiles, tile_h, tile_w;
 };
+
+// A pair whose tile index or crop origin would read outside its tile never touches memory: its crops
+// are taken as zero and its result carries coarse = INT32_MIN (the pair table lives in device memory,
+// so the host cannot validate it before the launch).
+__device__ __forceinline__ bool pair_ok(const RegParams &P, const sq_pair &pr) {
+    const Layout &L = P.L;
+    return pr.ref_tile >= 0 && pr.ref_tile < P.n_tiles && pr.mov_tile >= 0 && pr.mov_tile < P.n_tiles &&
+           pr.ref_y0 >= 0 && pr.ref_x0 >= 0 && pr.mov_y0 >= 0 && pr.mov_x0 >= 0 &&
+           pr.ref_y0 + L.n0 <= P.tile_h && pr.mov_y0 + L.n0 <= P.tile_h && pr.ref_x0 + L.n1 <= P.tile_w &&
+           pr.mov_x0 + L.n1 <= P.tile_w;
+}
 
 // ---------------------------------------------------------------------------------------------
 // line FFT in LDS
@@ -283,20 +295,24 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     cplx *tmp = x + n1;
     const int pair = blockIdx.y, r = blockIdx.x;
     const sq_pair pr = P.pairs[pair];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r * n1h;
+    cplx *B = A + (int64_t)L.n0 * n1h;
+    if (!pair_ok(P, pr)) {   // uniform per block
+        for (int k = tid; k < n1h; k += nt) A[k] = B[k] = {0.0, 0.0};
+        return;
+    }
     const T *ref = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.ref_tile])
                                : static_cast<const T *>(P.tile_base) + pr.ref_tile * P.tile_stride;
     const T *mov = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.mov_tile])
                                : static_cast<const T *>(P.tile_base) + pr.mov_tile * P.tile_stride;
     const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
     const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
-    const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t rbase = (int64_t)(pr.ref_y0 + r) * P.tile_pitch + pr.ref_x0;
     const int64_t mbase = (int64_t)(pr.mov_y0 + r) * P.tile_pitch + pr.mov_x0;
     for (int j = tid; j < n1; j += nt) x[j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     __syncthreads();
     line_fft<false>(x, tmp, n1, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
-    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r * n1h;
-    cplx *B = A + (int64_t)L.n0 * n1h;
     for (int k = tid; k < n1h; k += nt) {
         const cplx zk = x[k], zc = cconj(x[k ? n1 - k : 0]);
         // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
@@ -480,8 +496,9 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
         pk[0] = sy;
         pk[1] = sx;
         sq_pair_result &res = P.results[pair];
-        res.coarse[0] = sy;
-        res.coarse[1] = sx;
+        const bool ok = pair_ok(P, P.pairs[pair]);
+        res.coarse[0] = ok ? sy : INT32_MIN;
+        res.coarse[1] = ok ? sx : INT32_MIN;
         res.fine[0] = res.fine[1] = 0;
         // |cc| at the whole-pixel peak, with ifftn's 1/(n0 n1); sign is not recoverable from |.|,
         // the upsampled stage overwrites this with the complex value when u > 1
@@ -686,6 +703,9 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.L = L;
     P.n_pairs = a->n_pairs;
     P.normalization = a->normalization;
+    P.n_tiles = a->n_tiles;
+    P.tile_h = a->tile_h;
+    P.tile_w = a->tile_w;
     // columns per block: two [tc][n0] complex arrays (+ one scratch line for the direct DFT) in 144 KiB of LDS
     const int64_t scratch = is_pow2(L.n0) ? 0 : (int64_t)L.n0 * 16;
     int tc = (int)std::min<int64_t>(8, (144 * 1024 - scratch) / (2 * (int64_t)L.n0 * 16));

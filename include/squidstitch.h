@@ -147,7 +147,8 @@ typedef struct sq_pair {
 /* Result per pair.  shift = round(coarse*u)/u + (fine - fix(ceil(1.5u)/2))/u is formed on the
  * host in float64 exactly as skimage does (_phase_cross_correlation.py:232-250). */
 typedef struct sq_pair_result {
-    int32_t coarse[2]; /* whole-pixel peak after wrap-around (skimage :215-220)        */
+    int32_t coarse[2]; /* whole-pixel peak after wrap-around (skimage :215-220); INT32_MIN  */
+                       /* in both if the pair's tile index or crop lies outside its tile    */
     int32_t fine[2];   /* argmax index in the 15x15 upsampled neighbourhood (:244)     */
     double ccmax_re, ccmax_im; /* cross-correlation value at the refined peak          */
     double src_amp, tgt_amp;   /* sum |F|^2, sum |G|^2 (:252-254)                      */

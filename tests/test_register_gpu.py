@@ -171,3 +171,31 @@ def test_long_non_power_of_two_lines():
             got = registration.phase_cross_correlation(ref, mov, upsample_factor=10, normalization=norm)[0]
             np.testing.assert_array_equal(got, want, err_msg=f'{n0}x{n1} {norm}')
             assert want.tolist() == [-dy, -dx]
+
+
+def test_out_of_range_pairs_are_flagged_not_read():
+    """The pair table is device memory, so the library cannot validate it on the host: a pair whose
+    tile index or crop would leave its tile is skipped on the device and flagged (the Python binding
+    refuses such pairs earlier; this goes through the C-ABI underneath it)."""
+    import ctypes as C
+    import torch
+    dev = _dev()
+    rng = np.random.default_rng(0)
+    tiles = torch.from_numpy(rng.integers(0, 65536, (2, 64, 64)).astype(np.uint16)).to(dev)
+    mm = native.tile_minmax(tiles)
+    pairs = np.array([(0, 1, 0, 0, 0, 0), (0, 5, 0, 0, 0, 0), (0, 1, 40, 0, 0, 0), (0, 1, 0, 0, 0, -1), (1, 0, 16, 16, 16, 16)],
+                     dtype=native.PAIR_DTYPE)
+    L = native.lib()
+    n0 = n1 = 32
+    ws = torch.empty(int(L.sq_register_workspace_bytes(len(pairs), n0, n1, 10)), dtype=torch.uint8, device=dev)
+    pd = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(dev)
+    res = torch.zeros(len(pairs) * native.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    a = native._RegisterArgs()
+    a.tile_base_dev, a.tile_stride, a.n_tiles, a.tile_h, a.tile_w, a.tile_pitch, a.tile_dtype = tiles.data_ptr(), 64 * 64, 2, 64, 64, 64, native.SQ_U16
+    a.minmax_dev, a.pairs_dev, a.n_pairs, a.n0, a.n1 = mm.data_ptr(), pd.data_ptr(), len(pairs), n0, n1
+    a.upsample_factor, a.normalization = 10, native.SQ_NORM_PHASE
+    a.results_dev, a.workspace_dev, a.workspace_bytes = res.data_ptr(), ws.data_ptr(), ws.numel()
+    assert L.sq_register_pairs(C.byref(a), native._stream_ptr()) == 0
+    out = res.cpu().numpy().view(native.RESULT_DTYPE)
+    bad = np.iinfo(np.int32).min
+    assert [tuple(r['coarse']) == (bad, bad) for r in out] == [False, True, True, True, False]
