@@ -73,7 +73,6 @@ struct FuseParams {
     int32_t n_tiles, tile_h, tile_w, tile_pitch;
     int32_t canvas_pitch;
     const uint32_t *flat_class;   // per plane: 0 = every gain is a normal float (fast divide allowed)
-    int32_t plane_group;          // consecutive planes that share one flatfield (>= 1, divides n_planes)
 };
 
 template <typename T>
@@ -398,45 +397,27 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
-    // Persistent grid-stride walk over work slots: block b takes slots b, b + G, ...; the next
-    // descriptor and tile pointer are fetched while the current item streams.
-    // Slot order: planes come in groups of P.plane_group consecutive planes that share one
-    // flatfield (the z planes of a channel).  Inside a group the walk is item-major, plane-minor, in
-    // units of 8 items (slot % 8 == item position % 8, which keeps a tile-row block on "its" XCD):
-    //     slot = ((group * ceil(n_items/8) + item/8) * plane_group + z) * 8 + item%8
-    // so the flatfield rows an item needs are used by plane_group x ~290 consecutive slots instead
-    // of ~290: workgroups drifting apart over a 35 ms launch no longer widen an XCD's flatfield
-    // working set beyond its L2 (PMC: fetched bytes per launch 125 GB -> see DESIGN.md 5.1).
-    const int64_t units = (n_items + 7) / 8;                 // 8-item units per plane
-    const int64_t per_group = units * 8 * P.plane_group;     // slots per plane group
-    auto decode = [&](int64_t slot, int &plane) -> int64_t { // -> item position, or -1 for a padding slot
-        const int64_t g = slot / per_group, r = slot - g * per_group;
-        const int64_t u = r / (8 * P.plane_group), rr = r - u * 8 * P.plane_group;
-        plane = (int)(g * P.plane_group + rr / 8);
-        const int64_t item = u * 8 + (rr & 7);
-        return item < n_items ? item : -1;
-    };
-    int64_t slot = blockIdx.x;
-    int plane = 0;
-    int64_t pos = -1;
-    for (; slot < n_work; slot += gridDim.x)
-        if ((pos = decode(slot, plane)) >= 0) break;
-    if (pos < 0) return;
-    Item it = P.items[pos];
+    // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
+    // pointer are fetched while the current item streams
+    int64_t work = blockIdx.x;
+    if (work >= n_work) return;
+    int plane = (int)(work / n_items);
+    Item it = P.items[work - plane * n_items];
     const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
     while (true) {
+        const int64_t nwork = work + gridDim.x;
+        const bool more = nwork < n_work;
         int nplane = plane;
-        int64_t npos = -1;
-        for (slot += gridDim.x; slot < n_work; slot += gridDim.x)
-            if ((npos = decode(slot, nplane)) >= 0) break;
         Item nit = it;
         const T *ntile = nullptr;
-        if (npos >= 0) {
-            nit = P.items[npos];
+        if (more) {
+            nplane = (int)(nwork / n_items);
+            nit = P.items[nwork - nplane * n_items];
             ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
         }
         process_item<T, FLAT>(P, plane, it, tile, wave, lane);
-        if (npos < 0) break;
+        if (!more) break;
+        work = nwork;
         plane = nplane;
         it = nit;
         tile = ntile;
@@ -579,10 +560,9 @@ __global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P, c
 // Persistent launch: as many workgroups as the chip keeps resident (queried once per kernel),
 // each walking the (plane, item) list with a grid stride.
 template <typename K>
-int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream, bool slotted = false) {
-    // slotted (overwrite kernel): work slots are padded to whole 8-item units per plane
-    const int64_t n_work = (slotted ? (n_items + 7) / 8 * 8 : n_items) * n_planes;
-    if (n_items == 0 || n_planes == 0) return SQ_OK;
+int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream) {
+    const int64_t n_work = n_items * n_planes;
+    if (n_work == 0) return SQ_OK;
     static thread_local std::map<const void *, int> resident;
     const void *key = reinterpret_cast<const void *>(kernel);
     auto it = resident.find(key);
@@ -705,14 +685,6 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.tile_pitch = a->tile_pitch;
     P.canvas_pitch = a->canvas_pitch;
     P.flat_class = nullptr;
-    P.plane_group = 1;
-    if (a->plane_group > 1) {
-        if (a->n_planes % a->plane_group)
-            return fail(SQ_ERR_INVALID, "sq_fuse_planes: plane_group %d does not divide n_planes %d", a->plane_group, a->n_planes);
-        P.plane_group = a->plane_group;
-    } else if (a->plane_group < 0) {
-        return fail(SQ_ERR_INVALID, "sq_fuse_planes: plane_group %d", a->plane_group);
-    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
     if (flat == 1 && a->scratch_dev && a->mode == SQ_FUSE_OVERWRITE && a->n_planes > 0) {
@@ -734,13 +706,13 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             return fail(SQ_ERR_INVALID, "sq_fuse_planes: overwrite mode keeps the tile dtype (canvas %d, tile %d)",
                         a->canvas_dtype, a->tile_dtype);
         if (u16) {
-            if (flat == 0) return launch(fuse_overwrite_kernel<uint16_t, 0>, P, h.n_items, a->n_planes, stream, true);
-            if (flat == 1) return launch(fuse_overwrite_kernel<uint16_t, 1>, P, h.n_items, a->n_planes, stream, true);
-            return launch(fuse_overwrite_kernel<uint16_t, 2>, P, h.n_items, a->n_planes, stream, true);
+            if (flat == 0) return launch(fuse_overwrite_kernel<uint16_t, 0>, P, h.n_items, a->n_planes, stream);
+            if (flat == 1) return launch(fuse_overwrite_kernel<uint16_t, 1>, P, h.n_items, a->n_planes, stream);
+            return launch(fuse_overwrite_kernel<uint16_t, 2>, P, h.n_items, a->n_planes, stream);
         }
-        if (flat == 0) return launch(fuse_overwrite_kernel<uint8_t, 0>, P, h.n_items, a->n_planes, stream, true);
-        if (flat == 1) return launch(fuse_overwrite_kernel<uint8_t, 1>, P, h.n_items, a->n_planes, stream, true);
-        return launch(fuse_overwrite_kernel<uint8_t, 2>, P, h.n_items, a->n_planes, stream, true);
+        if (flat == 0) return launch(fuse_overwrite_kernel<uint8_t, 0>, P, h.n_items, a->n_planes, stream);
+        if (flat == 1) return launch(fuse_overwrite_kernel<uint8_t, 1>, P, h.n_items, a->n_planes, stream);
+        return launch(fuse_overwrite_kernel<uint8_t, 2>, P, h.n_items, a->n_planes, stream);
     }
     // feather
     const bool f32out = a->canvas_dtype == SQ_F32;

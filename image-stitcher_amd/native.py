@@ -45,7 +45,7 @@ class _FuseArgs(C.Structure):
         ('canvas_dev', C.c_void_p), ('canvas_plane_stride', C.c_int64),
         ('canvas_h', C.c_int32), ('canvas_w', C.c_int32), ('canvas_pitch', C.c_int32),
         ('canvas_dtype', C.c_int32), ('n_planes', C.c_int32), ('mode', C.c_int32),
-        ('scratch_dev', C.c_void_p), ('scratch_bytes', C.c_int64), ('plane_group', C.c_int32),
+        ('scratch_dev', C.c_void_p), ('scratch_bytes', C.c_int64),
     ]
 
 
@@ -263,17 +263,6 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
         keep.append(scratch)
         a.scratch_dev = scratch.data_ptr()
         a.scratch_bytes = scratch.numel()
-        # runs of consecutive planes that share one flatfield (the z planes of a channel)
-        runs, prev = [], object()
-        for f in flats:
-            key = None if f is None else f.data_ptr()
-            if key == prev:
-                runs[-1] += 1
-            else:
-                runs.append(1)
-                prev = key
-        if len(set(runs)) == 1 and runs[0] > 1:
-            a.plane_group = runs[0]
     a.canvas_dev = canvas.data_ptr()
     a.canvas_plane_stride = hc * wc
     a.canvas_h, a.canvas_w, a.canvas_pitch = hc, wc, wc

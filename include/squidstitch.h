@@ -110,11 +110,6 @@ typedef struct sq_fuse_args {
     /* float32 gains (all normal floats?) and use the shortened exact divide; NULL = generic divide   */
     void *scratch_dev;
     int64_t scratch_bytes;
-    /* optional hint: planes come in runs of plane_group consecutive planes that share one flatfield */
-    /* (the z planes of a channel); the kernel then walks a run item by item across its planes, which  */
-    /* keeps the flatfield rows in L2.  0 or 1 = no grouping; must divide n_planes.  Results do not    */
-    /* depend on it.                                                                                   */
-    int32_t plane_group;
 } sq_fuse_args;
 
 int64_t sq_fuse_scratch_bytes(int32_t n_planes);

@@ -304,26 +304,6 @@ def test_fuzz_geometry_dtype_flat_mode(seed):
             np.testing.assert_array_equal(got[p], want)
 
 
-def test_plane_groups_sharing_a_flatfield():
-    """2 channels x 3 z planes: planes of a channel share one gain image, so the kernel walks each
-    group item by item across its planes (plane_group = 3).  Same result as plane by plane."""
-    torch = _torch()
-    rng = np.random.default_rng(31)
-    th, tw, ch, cw, n = 40, 90, 150, 333, 11
-    rects = random_rects(rng, n, th, tw, ch - 10, cw - 10)
-    tiles = rng.integers(0, 65536, size=(6, n, th, tw)).astype(np.uint16)
-    f0 = (0.5 + rng.random((th, tw))).astype(np.float32)
-    f1 = (0.5 + rng.random((th, tw))).astype(np.float32)
-    dev = torch.device('cuda:0')
-    plan = native.FusePlan(rects, th, tw, ch, cw)
-    d0, d1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
-    canvas = torch.full((6, ch, cw), 9, dtype=torch.uint16, device=dev)
-    native.fuse_planes(plan, torch.from_numpy(tiles).to(dev), canvas, [d0, d0, d0, d1, d1, d1])
-    got = canvas.cpu().numpy()
-    for p in range(6):
-        np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, f0 if p < 3 else f1))
-
-
 def test_planes_sharing_a_flatfield():
     """2 channels x 3 z planes: the planes of a channel share one gain image (pointer table with
     repeated entries)."""
