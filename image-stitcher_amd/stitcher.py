@@ -336,6 +336,12 @@ class Stitcher:
             sorted(self.x_positions), sorted(self.y_positions), self.input_width, self.input_height,
             self.pixel_size_um, self.pixel_binning)
         print(f"[registration] crop widths from the stage pitch: {max_x_overlap} px horizontal, {max_y_overlap} px vertical")
+        if getattr(self, 'dynamic_registration', False):
+            # --dynamic-registration (parsed but never read by the reference): every adjacent pair of
+            # the registration plane, one batch per direction, per-axis median of the integer shifts
+            self._calculate_shifts_all_pairs(t, region, x_positions, y_positions, max_x_overlap, max_y_overlap)
+            print(f"[registration] all pairs: h_shift = {self.h_shift}, v_shift = {self.v_shift}")
+            return
         cx, cy = (len(x_positions) - 1) // 2, (len(y_positions) - 1) // 2
         center_x, center_y = x_positions[cx], y_positions[cy]
         right_x = bottom_y = None
@@ -363,6 +369,56 @@ class Stitcher:
             else:
                 print(f"Warning: region {region}: tiles of the reversed row missing, h_shift_rev stays {self.h_shift_rev}")
         print(f"[registration] h_shift = {self.h_shift}, v_shift = {self.v_shift}")
+
+    def _calculate_shifts_all_pairs(self, t, region, xs, ys, max_x_overlap, max_y_overlap):
+        """Extension: registration over ALL adjacent tile pairs of the registration plane (batched on the
+        device), reduced to the reference's state (h_shift, v_shift[, h_shift_rev]) by a per-axis median --
+        a single bad tile (dust, empty field) then cannot derail the whole mosaic."""
+        import torch
+        n_rows, n_cols = len(ys), len(xs)
+        at = {}
+        for v in self.get_region_data(t, region).values():
+            if v['channel'] == self.registration_channel and v['z_level'] == self.registration_z_level:
+                at[(ys.index(v['y']), xs.index(v['x']))] = v['filepath']
+        index, images = {}, []
+        for key in sorted(at):
+            index[key] = len(images)
+            img = read_image(at[key])
+            images.append(img if img.ndim == 2 else img[..., 0])
+        if not images:
+            return
+        tiles = torch.from_numpy(np.ascontiguousarray(np.stack(images))).to(self.device)
+        minmax = native.tile_minmax(tiles)
+        cy = (n_rows - 1) // 2
+        s_pattern = self.scan_pattern == 'S-Pattern'
+
+        def median_int(values):
+            return int(np.sort(np.asarray(values))[(len(values) - 1) // 2])    # lower median: stays an integer
+
+        def reduce(pairs_rc, make, convert, width):
+            rows = [(make(index[a], index[b], self.input_height, self.input_width, width), a) for a, b in pairs_rc
+                    if a in index and b in index]
+            if not rows:
+                return None, []
+            n0, n1 = rows[0][0][1], rows[0][0][2]
+            batch = np.array([r[0][0] for r in rows], dtype=native.PAIR_DTYPE)
+            shifts, _, _ = registration.register_pairs(tiles, batch, n0, n1, 10, self.normalization, minmax)
+            return [convert(sft, n1 if make is registration.horizontal_pair else n0) for sft in shifts], [r[1] for r in rows]
+
+        h_pairs = [((r, c), (r, c + 1)) for r in range(n_rows) for c in range(n_cols - 1)]
+        v_pairs = [((r, c), (r + 1, c)) for r in range(n_rows - 1) for c in range(n_cols)]
+        hs, h_at = reduce(h_pairs, registration.horizontal_pair, registration.horizontal_shift_from, max_x_overlap)
+        vs, _ = reduce(v_pairs, registration.vertical_pair, registration.vertical_shift_from, max_y_overlap)
+        if hs:
+            fwd = [s for s, (r, _) in zip(hs, h_at) if not s_pattern or r % 2 == cy % 2]
+            rev = [s for s, (r, _) in zip(hs, h_at) if s_pattern and r % 2 != cy % 2]
+            if fwd:
+                self.h_shift = (median_int([s[0] for s in fwd]), median_int([s[1] for s in fwd]))
+            if rev:
+                self.h_shift_rev = (median_int([s[0] for s in rev]), median_int([s[1] for s in rev]))
+                self.h_shift_rev_odd = cy % 2 == 0
+        if vs:
+            self.v_shift = (median_int([s[0] for s in vs]), median_int([s[1] for s in vs]))
 
     # -------------------------------------------------------------- flatfield
     def apply_flatfield_correction(self, tile, channel_idx):

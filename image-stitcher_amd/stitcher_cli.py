@@ -19,7 +19,7 @@ FLAGS = (
     (('--use-registration', '-r'), dict(action='store_true', help="register the centre tile pairs and place tiles by the measured shifts")),
     (('--registration-channel',), dict(help="channel the shifts are measured on (first channel when omitted)")),
     (('--registration-z-level',), dict(type=int, default=0, help="z plane the shifts are measured on")),
-    (('--dynamic-registration',), dict(action='store_true', help="accepted for compatibility (the reference stores and ignores it)")),
+    (('--dynamic-registration',), dict(action='store_true', help="register every adjacent tile pair and use the median shift (the reference accepts and ignores this flag)")),
     (('--scan-pattern', '-s'), dict(choices=['Unidirectional', 'S-Pattern'], default='Unidirectional', help="stage scan order")),
     (('--merge-timepoints', '-mt'), dict(action='store_true', help="request one dataset over all timepoints")),
     (('--merge-hcs-regions', '-mw'), dict(action='store_true', help="request one plate dataset over all wells")),

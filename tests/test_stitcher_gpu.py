@@ -130,3 +130,34 @@ def test_thread_style_start_wait_and_signals(tmp_path):
     assert path.endswith(os.path.join('0_stitched', 'R0_stitched.ome.zarr')) and dtype == np.uint16
     np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '0')), arrays['t0_R0_canvas'])
     assert (list(st.h_shift), list(st.v_shift)) == (info['h_shift'], info['v_shift'])
+
+
+def test_dynamic_registration_all_pairs_survives_a_bad_centre_tile(tmp_path):
+    """--dynamic-registration (ignored by the reference) = all adjacent pairs, median.  With the centre
+    tile replaced by an empty field the centre-pair result is garbage, the all-pairs result is still
+    the planted drift; on intact data both agree with the reference's golden shifts."""
+    from image_stitcher_amd.tiffio import write_tiff
+    info, _ = load_case('reg_spattern')           # 4 x 3 grid, S-Pattern: exercises the reversed-row split
+    spec = spec_of(info)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+
+    def shifts(dynamic):
+        st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, dynamic_registration=dynamic,
+                                          scan_pattern='S-Pattern'), normalization='phase')
+        st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+        st.calculate_shifts(st.timepoints[0], st.regions[0])
+        return tuple(st.h_shift), tuple(st.v_shift), tuple(st.h_shift_rev), int(st.h_shift_rev_odd)
+
+    golden = (tuple(info['h_shift']), tuple(info['v_shift']), tuple(info['h_shift_rev']), info['h_shift_rev_odd'])
+    assert shifts(False) == golden
+    dyn = shifts(True)
+    assert dyn[0] == golden[0] and dyn[2] == golden[2] and dyn[3] == golden[3]
+    # (v_shift: this synthetic S-Pattern has two populations of vertical pairs -- rows of different parity
+    #  have different pitches by construction -- so the median legitimately differs from the centre pair)
+    # wipe the centre tile (row 1, col 1 -> fov of the reversed row)
+    centre_fov = spec.fov_index(1, 1)
+    path = os.path.join(root, '0', f'R0_{centre_fov}_0_{synth.channel_file_token(spec.channels[0])}.tiff')
+    write_tiff(path, np.full((spec.tile_h, spec.tile_w), 1234, dtype=np.uint16))
+    assert shifts(False)[0] != golden[0]          # the reference's centre-pair scheme is derailed
+    assert shifts(True) == dyn                    # the all-pairs median is not
