@@ -322,3 +322,41 @@ def test_planes_sharing_a_flatfield():
     got = canvas.cpu().numpy()
     for p in range(6):
         np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, f0 if p < 3 else f1))
+
+
+def test_padded_tile_and_canvas_pitches_through_the_c_abi():
+    """tile_pitch > tile_w and canvas_pitch > canvas_w (the Python binding always passes dense buffers,
+    the C-ABI does not require them): padding is neither read into the result nor written."""
+    import ctypes as C
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(2)
+    th, tw, tp, ch, cw, cp, n, planes = 33, 70, 77, 90, 151, 160, 6, 2
+    rects = random_rects(rng, n, th, tw, ch - 5, cw - 5)
+    tiles = rng.integers(0, 65536, size=(planes, n, th, tp)).astype(np.uint16)        # padded rows
+    flat = (0.5 + rng.random((th, tw))).astype(np.float32)
+    plan = native.FusePlan(rects, th, tw, ch, cw)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    d_canvas = torch.full((planes, ch, cp), 0xBEEF, dtype=torch.uint16, device=dev)
+    d_flat = torch.from_numpy(flat).to(dev)
+    fp = native.pointer_table([d_flat, d_flat], dev)
+    table = plan.device_table(dev)
+    L = native.lib()
+    scratch = torch.empty(int(L.sq_fuse_scratch_bytes(planes)), dtype=torch.uint8, device=dev)
+    a = native._FuseArgs()
+    a.plan, a.table_dev, a.table_bytes = plan.handle, table.data_ptr(), table.numel()
+    a.tile_base_dev, a.tile_plane_stride, a.tile_stride = d_tiles.data_ptr(), n * th * tp, th * tp
+    a.n_tiles, a.tile_h, a.tile_w, a.tile_pitch, a.tile_dtype = n, th, tw, tp, native.SQ_U16
+    a.flat_ptrs_dev, a.flat_dtype = fp.data_ptr(), native.SQ_F32
+    a.canvas_dev, a.canvas_plane_stride, a.canvas_h, a.canvas_w, a.canvas_pitch = d_canvas.data_ptr(), ch * cp, ch, cw, cp
+    a.canvas_dtype, a.n_planes, a.mode = native.SQ_U16, planes, native.SQ_FUSE_OVERWRITE
+    a.scratch_dev, a.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    assert L.sq_fuse_planes(C.byref(a), native._stream_ptr()) == 0, L.sq_last_error()
+    torch.cuda.synchronize()
+    got = d_canvas.cpu().numpy()
+    for p in range(planes):
+        want = O.fuse_plane_overwrite(list(tiles[p][:, :, :tw]), rects, ch, cw, flat)
+        np.testing.assert_array_equal(got[p][:, :cw], want)
+        assert (got[p][:, cw:] == 0xBEEF).all()                 # the pitch padding is never written
+    a.canvas_pitch = cw - 1
+    assert L.sq_fuse_planes(C.byref(a), native._stream_ptr()) == -1 and b'pitch' in L.sq_last_error()
