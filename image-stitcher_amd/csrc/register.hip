@@ -625,6 +625,23 @@ __global__ __launch_bounds__(256) void upsample_peak_kernel(RegParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stand-alone normalize_image (the registration pipeline fuses the same arithmetic into K1)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_kernel(const void *const *tile_ptrs, const void *tile_base,
+                                                        int64_t tile_stride, int tile_h, int tile_w, int pitch,
+                                                        const uint32_t *minmax, T *out) {
+    const int t = blockIdx.y;
+    const T *tile = tile_ptrs ? static_cast<const T *>(tile_ptrs[t]) : static_cast<const T *>(tile_base) + t * tile_stride;
+    const double lo = minmax[2 * t], range = (double)minmax[2 * t + 1] - lo;
+    const int64_t n = (int64_t)tile_h * tile_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / tile_w), x = (int)(i - (int64_t)y * tile_w);
+        out[(int64_t)t * n + i] = (T)normalised<T>(tile, (int64_t)y * pitch + x, lo, range);
+    }
+}
+
 int check_line(int n, const char *axis) {
     if (n < 2) return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %s length %d < 2", axis, n);
     if (is_pow2(n) ? n > MAX_POW2 : n > MAX_DIRECT)
@@ -659,6 +676,30 @@ extern "C" int sq_tile_minmax(const void *const *tile_ptrs_dev, const void *tile
                            tile_w, tile_pitch, out_minmax_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_tile_minmax: launch failed: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+extern "C" int sq_normalize_tiles(const void *const *tile_ptrs_dev, const void *tile_base_dev, int64_t tile_stride,
+                                  int32_t n_tiles, int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype,
+                                  const uint32_t *minmax_dev, void *out_dev, void *stream_) {
+    if ((!tile_ptrs_dev && !tile_base_dev) || !minmax_dev || !out_dev || n_tiles < 0 || tile_h <= 0 || tile_w <= 0 ||
+        tile_pitch < tile_w)
+        return fail(SQ_ERR_INVALID, "sq_normalize_tiles: bad arguments (n_tiles=%d %dx%d pitch %d)", n_tiles, tile_h, tile_w,
+                    tile_pitch);
+    if (tile_dtype != SQ_U8 && tile_dtype != SQ_U16) return fail(SQ_ERR_UNSUPPORTED, "sq_normalize_tiles: dtype %d", tile_dtype);
+    if (n_tiles == 0) return SQ_OK;
+    if (n_tiles > 65535) return fail(SQ_ERR_UNSUPPORTED, "sq_normalize_tiles: more than 65535 tiles per call");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)tile_h * tile_w + 1023) / 1024));
+    dim3 grid(bx, n_tiles);
+    if (tile_dtype == SQ_U16)
+        hipLaunchKernelGGL(normalize_kernel<uint16_t>, grid, dim3(256), 0, s, tile_ptrs_dev, tile_base_dev, tile_stride, tile_h,
+                           tile_w, tile_pitch, minmax_dev, static_cast<uint16_t *>(out_dev));
+    else
+        hipLaunchKernelGGL(normalize_kernel<uint8_t>, grid, dim3(256), 0, s, tile_ptrs_dev, tile_base_dev, tile_stride, tile_h,
+                           tile_w, tile_pitch, minmax_dev, static_cast<uint8_t *>(out_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_normalize_tiles: launch failed: %s", hipGetErrorString(e));
     return SQ_OK;
 }
 

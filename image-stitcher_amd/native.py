@@ -72,6 +72,8 @@ EXPORTS = {
     'sq_fuse_planes': (C.c_int, [C.POINTER(_FuseArgs), C.c_void_p]),
     'sq_tile_minmax': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_void_p, C.c_void_p]),
+    'sq_normalize_tiles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'sq_register_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -293,6 +295,19 @@ def tile_minmax(tiles, stream=None, tile_ptrs=None, shape=None, np_dtype=None):
     out = torch.empty((n, 2), dtype=torch.int32, device=device)
     _check(L.sq_tile_minmax(ptrs, base, stride, n, h, w, w, dt, out.data_ptr(), _stream_ptr(stream)),
            'sq_tile_minmax')
+    return out
+
+
+def normalize_tiles(tiles, minmax=None, stream=None):
+    """normalize_image on a contiguous device stack [N, H, W] -> normalised stack of the same dtype."""
+    import torch
+    L = lib()
+    n, h, w = (int(v) for v in tiles.shape)
+    if minmax is None:
+        minmax = tile_minmax(tiles, stream)
+    out = torch.empty_like(tiles)
+    _check(L.sq_normalize_tiles(None, tiles.data_ptr(), h * w, n, h, w, w, sq_dtype_of(np_dtype_of_torch(tiles.dtype)),
+                                minmax.data_ptr(), out.data_ptr(), _stream_ptr(stream)), 'sq_normalize_tiles')
     return out
 
 

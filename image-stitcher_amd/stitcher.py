@@ -286,13 +286,15 @@ class Stitcher:
 
     # ---------------------------------------------------------- registration
     def normalize_image(self, img):
-        """(stitcher.py:613-617), host arithmetic (debug / API parity; the device path fuses
-        this into the FFT load)."""
-        img = np.asarray(img)
-        lo, hi = img.min(), img.max()
-        full_scale = np.iinfo(self.dtype).max if np.issubdtype(self.dtype, np.integer) else 1
-        with np.errstate(all='ignore'):     # hi == lo -> 0/0, exactly like the reference
-            return (((img - lo) / (hi - lo)) * full_scale).astype(self.dtype)
+        """(stitcher.py:613-617) on the device: full-tile min/max, then the float64 stretch and the
+        truncating cast.  ``calculate_*_shift`` never call this: the registration kernels fuse the same
+        arithmetic into their first pass."""
+        import torch
+        img = np.ascontiguousarray(img)
+        if img.ndim != 2 or img.dtype not in (np.uint8, np.uint16):
+            raise ValueError(f"normalize_image takes a 2-D uint8/uint16 image, got {img.dtype} {img.shape}")
+        tiles = torch.from_numpy(img[None]).to(self.device)
+        return native.normalize_tiles(tiles)[0].cpu().numpy()
 
     def _register_two(self, img_a, img_b, max_overlap, vertical: bool):
         import torch

@@ -131,6 +131,14 @@ int sq_tile_minmax(const void *const *tile_ptrs_dev, const void *tile_base_dev, 
                    int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype,
                    uint32_t *out_minmax_dev, void *stream);
 
+/* normalize_image (stitcher.py:613-617) on whole tiles: out_dev[i] (dense tile_h x tile_w, same dtype) =
+ * ((tile - min) / (max - min) * dtype_max) truncated, in float64 like numpy; minmax from sq_tile_minmax.
+ * The registration pipeline fuses the same arithmetic into its first kernel; this entry point exists for
+ * callers of the method itself. */
+int sq_normalize_tiles(const void *const *tile_ptrs_dev, const void *tile_base_dev, int64_t tile_stride, int32_t n_tiles,
+                       int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype,
+                       const uint32_t *minmax_dev, void *out_dev, void *stream);
+
 typedef enum sq_normalization {
     SQ_NORM_NONE = 0, /* scikit-image <= 0.18                                       */
     SQ_NORM_PHASE = 1 /* scikit-image >= 0.19 default: P /= max(|P|, 100 eps)       */

@@ -199,3 +199,17 @@ def test_out_of_range_pairs_are_flagged_not_read():
     out = res.cpu().numpy().view(native.RESULT_DTYPE)
     bad = np.iinfo(np.int32).min
     assert [tuple(r['coarse']) == (bad, bad) for r in out] == [False, True, True, True, False]
+
+
+def test_normalize_tiles_equals_reference_golden_and_oracle():
+    import torch
+    v = np.load(os.path.join(GOLDEN, 'normalize_vectors.npz'))
+    for dt in ('uint16', 'uint8'):
+        got = native.normalize_tiles(torch.from_numpy(v[f'in_{dt}'][None]).to(_dev()))[0].cpu().numpy()
+        np.testing.assert_array_equal(got, v[f'out_{dt}'])
+    rng = np.random.default_rng(6)
+    stack = rng.integers(100, 60000, size=(5, 37, 61)).astype(np.uint16)
+    stack[3] = 777                                   # max == min: 0/0 -> 0 like the reference's cast
+    got = native.normalize_tiles(torch.from_numpy(stack).to(_dev())).cpu().numpy()
+    for i in range(5):
+        np.testing.assert_array_equal(got[i], O.normalize_image(stack[i], np.uint16))
