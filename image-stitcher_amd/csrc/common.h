@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/squidstitch.h"
@@ -78,7 +79,26 @@ static_assert(sizeof(Item) == 32, "Item layout");
 
 }  // namespace sq
 
+// TableHeader + spans + refs + items, exactly what goes to the device.  Plain malloc'd storage: the
+// builder writes every byte itself, so nothing is zero-filled first.
+struct sq_table {
+    char *ptr = nullptr;
+    size_t bytes = 0;
+    sq_table() = default;
+    sq_table(const sq_table &) = delete;
+    sq_table &operator=(const sq_table &) = delete;
+    ~sq_table() { free(ptr); }
+    bool allocate(size_t n) {
+        free(ptr);
+        ptr = static_cast<char *>(malloc(n ? n : 1));
+        bytes = ptr ? n : 0;
+        return ptr != nullptr;
+    }
+    size_t size() const { return bytes; }
+    const char *data() const { return ptr; }
+};
+
 struct sq_fuse_plan {
-    std::string table;  // TableHeader + spans + refs + items, exactly what goes to the device
+    sq_table table;
     const sq::TableHeader &header() const { return *reinterpret_cast<const sq::TableHeader *>(table.data()); }
 };

@@ -96,19 +96,25 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 
     // spans of the previous band that may continue into this one, sorted by xa (they are produced
     // left to right); the current band's intervals are produced left to right too, so matching a
-    // continuation is a two-pointer walk
+    // continuation is a two-pointer walk.  Owner lists are small fixed arrays: no heap traffic per interval.
+    struct Owners {
+        int n = 0;
+        int v[MAX_REFS];
+        bool operator==(const Owners &o) const {
+            if (n != o.n) return false;
+            for (int i = 0; i < n; ++i)
+                if (v[i] != o.v[i]) return false;
+            return true;
+        }
+    };
     struct Open {
         int xa, xb;
         int64_t index;   // into spans
-        int owner0;      // first owner (clipped-rect index) or -1
-        int nown;
+        Owners own;
     };
     std::vector<Open> open, open_next;
-    std::vector<int> open_owners, open_owners_next;   // owner lists of `open`, concatenated (feather)
-    std::vector<int> open_off, open_off_next;
 
-    std::vector<int> xs;
-    std::vector<int> owners, cur_owners;
+    std::vector<int> xs, owner_of, skip;
     for (size_t b = 0; b + 1 < ys.size(); ++b) {
         const int ya = ys[b], yb = ys[b + 1];
         while (next < by_y0.size() && cl[by_y0[next]].y0 <= ya) {
@@ -128,27 +134,15 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
 
         open_next.clear();
-        open_owners_next.clear();
-        open_off_next.clear();
         size_t op = 0;   // pointer into `open`
         int cur_xa = 0, cur_xb = 0;
+        Owners cur;
         bool have = false;
         auto flush = [&]() {
             if (!have) return;
             while (op < open.size() && open[op].xa < cur_xa) ++op;
-            bool cont = false;
-            if (op < open.size() && open[op].xa == cur_xa && open[op].xb == cur_xb &&
-                open[op].nown == (int)cur_owners.size()) {
-                cont = true;
-                const int *po = open_owners.data() + open_off[op];
-                for (size_t k = 0; k < cur_owners.size(); ++k)
-                    if (po[k] != cur_owners[k]) {
-                        cont = false;
-                        break;
-                    }
-            }
             int64_t index;
-            if (cont) {
+            if (op < open.size() && open[op].xa == cur_xa && open[op].xb == cur_xb && open[op].own == cur) {
                 index = open[op].index;
                 spans[index].h += yb - ya;
             } else {
@@ -157,56 +151,69 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 sp.dst_x = cur_xa;
                 sp.h = yb - ya;
                 sp.w = cur_xb - cur_xa;
-                sp.nref = (int)cur_owners.size();
+                sp.nref = cur.n;
                 sp.ref0 = (int)refs.size();
-                for (int o : cur_owners) {
-                    const Clipped &c = cl[o];
+                for (int k = 0; k < cur.n; ++k) {
+                    const Clipped &c = cl[cur.v[k]];
                     refs.push_back({c.tile, c.src_y + (ya - c.y0), c.src_x + (cur_xa - c.x0), 0});
                 }
                 index = (int64_t)spans.size();
                 spans.push_back(sp);
             }
-            open_off_next.push_back((int)open_owners_next.size());
-            open_owners_next.insert(open_owners_next.end(), cur_owners.begin(), cur_owners.end());
-            open_next.push_back({cur_xa, cur_xb, index, cur_owners.empty() ? -1 : cur_owners[0], (int)cur_owners.size()});
-            if (!cur_owners.empty()) covered += (int64_t)(yb - ya) * (cur_xb - cur_xa);
-            max_refs = std::max(max_refs, (int)cur_owners.size());
+            open_next.push_back({cur_xa, cur_xb, index, cur});
+            if (cur.n) covered += (int64_t)(yb - ya) * (cur_xb - cur_xa);
+            max_refs = std::max(max_refs, cur.n);
             have = false;
         };
-        for (size_t k = 0; k + 1 < xs.size(); ++k) {
-            const int xa = xs[k], xb = xs[k + 1];
-            owners.clear();
-            if (mode == SQ_FUSE_OVERWRITE) {
-                for (size_t a = active.size(); a-- > 0;) {   // last writer wins: search from the back
-                    const Clipped &c = cl[active[a]];
-                    if (c.x0 <= xa && c.x1 >= xb) {
-                        owners.push_back(active[a]);
-                        break;
-                    }
+        const size_t m = xs.size() - 1;   // elementary x intervals of this band
+        if (mode == SQ_FUSE_OVERWRITE) {
+            // last writer wins: paint the intervals from the last active rect to the first, each interval
+            // once (skip pointers jump over what is already painted)
+            owner_of.assign(m, -1);
+            skip.resize(m + 1);
+            for (size_t k = 0; k <= m; ++k) skip[k] = (int)k;
+            auto find = [&](int k) {
+                while (skip[k] != k) k = skip[k] = skip[skip[k]];
+                return k;
+            };
+            for (size_t a = active.size(); a-- > 0;) {
+                const Clipped &c = cl[active[a]];
+                const int lo = (int)(std::lower_bound(xs.begin(), xs.end(), c.x0) - xs.begin());
+                const int hi = (int)(std::lower_bound(xs.begin(), xs.end(), c.x1) - xs.begin());
+                for (int k = find(lo); k < hi; k = find(k + 1)) {
+                    owner_of[k] = active[a];
+                    skip[k] = k + 1;
                 }
+            }
+        }
+        for (size_t k = 0; k < m; ++k) {
+            const int xa = xs[k], xb = xs[k + 1];
+            Owners own;
+            if (mode == SQ_FUSE_OVERWRITE) {
+                if (owner_of[k] >= 0) own.v[own.n++] = owner_of[k];
             } else {
                 for (int i : active)
-                    if (cl[i].x0 <= xa && cl[i].x1 >= xb) owners.push_back(i);
+                    if (cl[i].x0 <= xa && cl[i].x1 >= xb) {
+                        if (own.n == MAX_REFS) {
+                            fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: more than %d tiles overlap at canvas (%d,%d)",
+                                 MAX_REFS, ya, xa);
+                            return nullptr;
+                        }
+                        own.v[own.n++] = i;
+                    }
             }
-            if ((int)owners.size() > MAX_REFS) {
-                fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: %zu tiles overlap at canvas (%d,%d); feather supports %d",
-                     owners.size(), ya, xa, MAX_REFS);
-                return nullptr;
-            }
-            if (have && cur_owners == owners && cur_xb == xa) {
+            if (have && cur == own && cur_xb == xa) {
                 cur_xb = xb;
             } else {
                 flush();
                 cur_xa = xa;
                 cur_xb = xb;
-                cur_owners = owners;
+                cur = own;
                 have = true;
             }
         }
         flush();
         open.swap(open_next);
-        open_owners.swap(open_owners_next);
-        open_off.swap(open_off_next);
     }
 
     const auto t_sweep = std::chrono::steady_clock::now();
@@ -277,8 +284,12 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     hd.off_items = hd.off_refs + hd.n_refs * (int64_t)sizeof(Ref);
     hd.covered_voxels = covered;
     const int64_t total = hd.off_items + hd.n_items * (int64_t)sizeof(Item);
-    plan->table.resize((size_t)total);
-    char *p = &plan->table[0];
+    if (!plan->table.allocate((size_t)total)) {
+        delete plan;
+        fail(SQ_ERR_INVALID, "sq_fuse_plan_create: out of host memory for a %lld-byte table", (long long)total);
+        return nullptr;
+    }
+    char *p = plan->table.ptr;
     std::memcpy(p, &hd, sizeof hd);
     if (!spans.empty()) std::memcpy(p + hd.off_spans, spans.data(), spans.size() * sizeof(Span));
     if (!refs.empty()) std::memcpy(p + hd.off_refs, refs.data(), refs.size() * sizeof(Ref));
