@@ -74,6 +74,8 @@ EXPORTS = {
                                  C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_normalize_tiles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'sq_downsample2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                 C.c_int32, C.c_int32, C.c_void_p]),
     'sq_register_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -308,6 +310,31 @@ def normalize_tiles(tiles, minmax=None, stream=None):
     out = torch.empty_like(tiles)
     _check(L.sq_normalize_tiles(None, tiles.data_ptr(), h * w, n, h, w, w, sq_dtype_of(np_dtype_of_torch(tiles.dtype)),
                                 minmax.data_ptr(), out.data_ptr(), _stream_ptr(stream)), 'sq_normalize_tiles')
+    return out
+
+
+def downsample2(planes, out=None, stream=None):
+    """Next pyramid level of ``planes`` [n, h, w] (uint8 / uint16 device tensor, any row pitch) ->
+    [n, h // 2, w // 2]: out[p, y, x] = planes[p, 2y+1, 2x+1], what ome_zarr's Scaler.nearest computes per
+    level (stitcher.py:797-798).  ``out`` may be a preallocated tensor (any row pitch)."""
+    import torch
+    L = lib()
+    if planes.dim() != 3 or planes.device.type != 'cuda':
+        raise ValueError("planes must be a [n, h, w] device tensor")
+    if planes.stride(2) != 1 and planes.shape[2] > 1:
+        raise ValueError("planes rows must be contiguous")
+    n, h, w = (int(v) for v in planes.shape)
+    if out is None:
+        out = torch.empty((n, h // 2, w // 2), dtype=planes.dtype, device=planes.device)
+    if tuple(out.shape) != (n, h // 2, w // 2) or out.dtype != planes.dtype or out.device != planes.device:
+        raise ValueError(f"out must be a {(n, h // 2, w // 2)} tensor of the input's dtype and device")
+    if out.numel() and out.stride(2) != 1 and out.shape[2] > 1:
+        raise ValueError("out rows must be contiguous")
+    if out.numel() == 0:
+        return out
+    _check(L.sq_downsample2(planes.data_ptr(), planes.stride(0), h, w, planes.stride(1), out.data_ptr(), out.stride(0),
+                            out.stride(1), n, sq_dtype_of(np_dtype_of_torch(planes.dtype)), _stream_ptr(stream)),
+           'sq_downsample2')
     return out
 
 

@@ -3,9 +3,14 @@
 Layout follows what the reference writes through ome_zarr.writer.write_multiscale
 (stitcher.py:771-859): a group with arrays "0".."n-1" (TCZYX), chunks (1,1,1,512,512),
 ``multiscales`` axes t/c/z/y/x with units and per-level scale [1,1,dz,px*2^l,px*2^l],
-and an ``omero`` channel block.  Differences, on purpose: chunks are zlib-compressed
-(stdlib; the reference's default is Blosc, absent offline) and pyramid levels are plain
-stride-2 decimation.  This is the "next" row 8(f)1, not the hot path.
+and an ``omero`` channel block.  One difference, on purpose: chunks are zlib-compressed or
+raw (stdlib; the reference's default is Blosc, absent offline).
+
+Pyramid levels are what ome_zarr's ``Scaler.nearest`` produces (level l+1 = level l sampled at
+[2y+1, 2x+1], floor-halved shape); they are computed on the device (``native.downsample2``,
+csrc/pyramid.hip) -- this module only lays chunks out on disk.  ``PlaneStreamWriter`` is the
+"next" row 8(f)1: planes leave the GPU batch by batch (pyramid -> pinned D2H -> compression in
+host threads) while the next batch is being fused, so a region never has to exist in host memory.
 """
 from __future__ import annotations
 
@@ -33,45 +38,55 @@ def read_array(path: str) -> np.ndarray:
         if not os.path.exists(p):
             continue
         with open(p, 'rb') as fh:
-            block = np.frombuffer(zlib.decompress(fh.read()), dtype=dt).reshape(chunks)
+            raw = fh.read()
+        block = np.frombuffer(zlib.decompress(raw) if meta.get('compressor') else raw, dtype=dt).reshape(chunks)
         sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
         out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
     return out
 
 
 def level_shapes(shape: Sequence[int], num_levels: int) -> List[tuple]:
-    """TCZYX shapes of the pyramid levels: level l+1 is level l decimated by two in y and x."""
+    """TCZYX shapes of the pyramid levels: every level halves y and x of the one before, rounding
+    down (Scaler.nearest resizes to (Y // 2, X // 2))."""
     out = [tuple(int(v) for v in shape)]
     for _ in range(1, max(1, num_levels)):
         t, c, z, y, x = out[-1]
         if y < 2 or x < 2:
             break
-        out.append((t, c, z, (y + 1) // 2, (x + 1) // 2))
+        out.append((t, c, z, y // 2, x // 2))
     return out
 
 
-def _zarray_meta(shape, chunks, dtype, level=1):
+def _compressor(compression: str, level: int = 1):
+    if compression in (None, 'none', 'raw'):
+        return None
+    if compression == 'zlib':
+        return {'id': 'zlib', 'level': int(level)}
+    raise ValueError(f"compression must be 'zlib' or 'none', got {compression!r}")
+
+
+def _zarray_meta(shape, chunks, dtype, compression='zlib', level=1):
     dtype = np.dtype(dtype)
     chunks = tuple(int(min(c, s)) if s else int(c) for c, s in zip(chunks, shape))
     return chunks, {
         'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks),
         'dtype': dtype.newbyteorder('<').str if dtype.itemsize > 1 else dtype.str,
-        'compressor': {'id': 'zlib', 'level': level}, 'fill_value': 0, 'order': 'C', 'filters': None,
+        'compressor': _compressor(compression, level), 'fill_value': 0, 'order': 'C', 'filters': None,
         'dimension_separator': '/'}
 
 
 def create_store(path: str, shape: Sequence[int], dtype, *, pixel_size_um: float, dz_um: float = 1.0,
                  channel_names: Sequence[str] = (), channel_colors: Sequence[int] = (), num_levels: int = 1,
-                 chunks=(1, 1, 1, 512, 512), name: str = 'stitched') -> List[tuple]:
+                 chunks=(1, 1, 1, 512, 512), name: str = 'stitched', compression: str = 'zlib') -> List[tuple]:
     """Group + array metadata of a multiscale OME-Zarr image, no chunks yet.  Returns the level
-    shapes.  Chunks are then added plane by plane (``write_planes``), by any number of processes."""
+    shapes.  Chunks are then added plane by plane (``write_plane_levels``), by any number of processes."""
     os.makedirs(path, exist_ok=True)
     _write_json(os.path.join(path, '.zgroup'), {'zarr_format': 2})
     shapes = level_shapes(shape, num_levels)
     datasets = []
     for lv, shp in enumerate(shapes):
         os.makedirs(os.path.join(path, str(lv)), exist_ok=True)
-        _write_json(os.path.join(path, str(lv), '.zarray'), _zarray_meta(shp, chunks, dtype)[1])
+        _write_json(os.path.join(path, str(lv), '.zarray'), _zarray_meta(shp, chunks, dtype, compression)[1])
         sc = 2 ** lv
         datasets.append({'path': str(lv), 'coordinateTransformations': [
             {'type': 'scale', 'scale': [1, 1, dz_um, pixel_size_um * sc, pixel_size_um * sc]}]})
@@ -95,59 +110,199 @@ def create_store(path: str, shape: Sequence[int], dtype, *, pixel_size_um: float
     return shapes
 
 
-def write_planes(path: str, planes: np.ndarray, coords: Sequence[tuple], num_levels: int = 1,
-                 chunks=(1, 1, 1, 512, 512), level: int = 1, workers: Optional[int] = None) -> None:
-    """Write the chunks of whole (t, c, z) planes (``planes[i]`` is the 2-D plane at ``coords[i]``) into
-    every pyramid level of a store made by ``create_store``.  Chunks never span planes (chunk shape
-    (1,1,1,cy,cx)), so different processes can write different planes of one store concurrently."""
-    from concurrent.futures import ThreadPoolExecutor
+def chunk_jobs(levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1, 1, 1, 512, 512)) -> list:
+    """One job per chunk of whole (t, c, z) planes: ``levels[l][i]`` is the 2-D plane ``coords[i]`` at
+    pyramid level l.  Chunks never span planes (chunk shape (1,1,1,cy,cx)), so different processes can
+    write different planes of one store concurrently."""
     if tuple(chunks[:3]) != (1, 1, 1):
         raise ValueError("plane-wise writing needs chunks of shape (1, 1, 1, cy, cx)")
     jobs = []
-    for i, (t, c, z) in enumerate(coords):
-        lvl = planes[i]
-        for lv in range(max(1, num_levels)):
-            cy, cx = min(chunks[3], lvl.shape[0]), min(chunks[4], lvl.shape[1])
-            for y in range(0, lvl.shape[0], cy):
-                for x in range(0, lvl.shape[1], cx):
-                    jobs.append((lv, t, c, z, y // cy, x // cx, lvl, y, x, cy, cx))
-            if lvl.shape[0] < 2 or lvl.shape[1] < 2:
-                break
-            lvl = lvl[::2, ::2]
+    for lv, arr in enumerate(levels):
+        if arr.ndim != 3 or len(arr) < len(coords):
+            raise ValueError(f"level {lv}: expected [n_planes, y, x] with n_planes >= {len(coords)}, got {arr.shape}")
+        cy, cx = min(chunks[3], arr.shape[1]), min(chunks[4], arr.shape[2])
+        if cy == 0 or cx == 0:
+            continue
+        for i, (t, c, z) in enumerate(coords):
+            for y in range(0, arr.shape[1], cy):
+                for x in range(0, arr.shape[2], cx):
+                    jobs.append((lv, t, c, z, y // cy, x // cx, arr[i], y, x, cy, cx))
+    return jobs
 
-    def emit(job):
-        lv, t, c, z, iy, ix, lvl, y, x, cy, cx = job
-        block = lvl[y:y + cy, x:x + cx]
-        if not block.any():
-            return
-        if block.shape != (cy, cx):
-            full = np.zeros((cy, cx), dtype=lvl.dtype)
-            full[:block.shape[0], :block.shape[1]] = block
-            block = full
-        cdir = os.path.join(path, str(lv), str(t), str(c), str(z), str(iy))
-        os.makedirs(cdir, exist_ok=True)
-        with open(os.path.join(cdir, str(ix)), 'wb') as fh:
-            fh.write(zlib.compress(np.ascontiguousarray(block).tobytes(), level))
 
+def emit_chunk(path: str, job, compression: str = 'zlib', level: int = 1) -> int:
+    """Write one chunk (all-zero chunks are left to fill_value).  Returns the bytes written."""
+    lv, t, c, z, iy, ix, plane, y, x, cy, cx = job
+    block = plane[y:y + cy, x:x + cx]
+    if not block.any():
+        return 0
+    if block.shape != (cy, cx):
+        full = np.zeros((cy, cx), dtype=plane.dtype)
+        full[:block.shape[0], :block.shape[1]] = block
+        block = full
+    cdir = os.path.join(path, str(lv), str(t), str(c), str(z), str(iy))
+    os.makedirs(cdir, exist_ok=True)
+    raw = memoryview(np.ascontiguousarray(block)).cast('B')     # no second copy: file write / zlib read the buffer
+    data = raw if compression in (None, 'none', 'raw') else zlib.compress(raw, level)
+    with open(os.path.join(cdir, str(ix)), 'wb') as fh:
+        fh.write(data)
+    return len(data)
+
+
+def write_plane_levels(path: str, levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1, 1, 1, 512, 512),
+                       compression: str = 'zlib', level: int = 1, workers: Optional[int] = None, pool=None) -> int:
+    """Write the chunks of whole planes, every pyramid level given (see ``chunk_jobs``), into a store
+    made by ``create_store``.  Returns the bytes written."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = chunk_jobs(levels, coords, chunks)
+    if pool is not None:
+        return sum(pool.map(lambda j: emit_chunk(path, j, compression, level), jobs))
     n = workers if workers is not None else min(32, os.cpu_count() or 4)
     if n <= 1 or len(jobs) < 4:
-        for j in jobs:
-            emit(j)
-    else:
-        with ThreadPoolExecutor(max_workers=n) as pool:
-            list(pool.map(emit, jobs))
+        return sum(emit_chunk(path, j, compression, level) for j in jobs)
+    with ThreadPoolExecutor(max_workers=n) as tp:
+        return sum(tp.map(lambda j: emit_chunk(path, j, compression, level), jobs))
 
 
-def write_ome_zarr(path: str, image: np.ndarray, *, pixel_size_um: float, dz_um: float = 1.0,
+def device_levels(planes_dev, n_levels: int, out: Optional[list] = None) -> list:
+    """[planes_dev] + its n_levels - 1 pyramid levels, computed on the device (sq_downsample2)."""
+    from . import native
+    levels = [planes_dev]
+    for lv in range(1, n_levels):
+        levels.append(native.downsample2(levels[-1], None if out is None else out[lv - 1][:len(planes_dev)]))
+    return levels
+
+
+def write_ome_zarr(path: str, image, *, pixel_size_um: float, dz_um: float = 1.0,
                    channel_names: Sequence[str] = (), channel_colors: Sequence[int] = (),
-                   num_levels: int = 1, chunks=(1, 1, 1, 512, 512), name: str = 'stitched') -> str:
-    """Write a (T, C, Z, Y, X) array as a multiscale OME-Zarr image."""
+                   num_levels: int = 1, chunks=(1, 1, 1, 512, 512), name: str = 'stitched', compression: str = 'zlib',
+                   device=None) -> str:
+    """Write a (T, C, Z, Y, X) array (numpy, or a device tensor) as a multiscale OME-Zarr image.  The
+    pyramid levels come from the device kernel, a batch of planes at a time; with ``num_levels`` 1 no
+    GPU is touched for a numpy input."""
     if image.ndim != 5:
-        raise ValueError(f"expected a 5-D TCZYX array, got {image.shape}")
-    shapes = create_store(path, image.shape, image.dtype, pixel_size_um=pixel_size_um, dz_um=dz_um,
-                          channel_names=channel_names, channel_colors=channel_colors, num_levels=num_levels,
-                          chunks=chunks, name=name)
-    t_, c_, z_ = image.shape[:3]
+        raise ValueError(f"expected a 5-D TCZYX array, got {tuple(image.shape)}")
+    on_device = hasattr(image, 'data_ptr')
+    dtype = np.dtype(str(image.dtype).replace('torch.', '')) if on_device else image.dtype
+    shape = tuple(int(v) for v in image.shape)
+    shapes = create_store(path, shape, dtype, pixel_size_um=pixel_size_um, dz_um=dz_um, channel_names=channel_names,
+                          channel_colors=channel_colors, num_levels=num_levels, chunks=chunks, name=name,
+                          compression=compression)
+    t_, c_, z_ = shape[:3]
     coords = [(t, c, z) for t in range(t_) for c in range(c_) for z in range(z_)]
-    write_planes(path, image.reshape((-1,) + image.shape[3:]), coords, num_levels=len(shapes), chunks=chunks)
+    planes = image.reshape((-1,) + shape[3:])
+    if len(shapes) == 1 and not on_device:
+        write_plane_levels(path, [planes], coords, chunks, compression)
+        return path
+    import torch
+    if not on_device:
+        from . import native
+        native.lib()   # fail loudly: the pyramid is a device kernel, there is no host decimation
+        device = device if device is not None else 'cuda:0'
+    batch = max(1, (1 << 30) // max(1, shape[3] * shape[4] * dtype.itemsize))
+    with PlaneStreamWriter(path, shapes, dtype, chunks=chunks, batch=batch, compression=compression,
+                           device=planes.device if on_device else device) as writer:
+        for b0 in range(0, len(coords), batch):
+            part = planes[b0:b0 + batch]
+            dst = writer.acquire(len(part))
+            dst.copy_(part if on_device else torch.from_numpy(np.ascontiguousarray(part)), non_blocking=False)
+            writer.submit(coords[b0:b0 + batch])
     return path
+
+
+class PlaneStreamWriter:
+    """Streams fused planes from the device into a store made by ``create_store``.
+
+    Two slots, each = a device canvas of ``batch`` planes, device buffers for its pyramid levels and
+    pinned host mirrors of all of them.  ``acquire(m)`` hands out the slot's canvas (waiting until the
+    slot's previous contents are on disk); the caller fuses into it on the current stream and calls
+    ``submit(coords)``, which enqueues the pyramid kernels and the D2H copies behind the fusion and
+    returns at once; a dispatcher thread waits for the copies and fans the chunks out to the
+    compression threads.  So batch k is compressed and written while batch k+1 is read, copied and fused.
+    """
+
+    def __init__(self, path: str, shapes: Sequence[tuple], dtype, *, chunks=(1, 1, 1, 512, 512), batch: int = 1,
+                 compression: str = 'zlib', level: int = 1, device='cuda:0', workers: Optional[int] = None, slots: int = 2):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        import torch
+        from . import native
+        self.path, self.chunks, self.compression, self.level = path, tuple(chunks), compression, level
+        self.batch = int(batch)
+        self.bytes_written = 0
+        tdtype = native.torch_dtype_of(np.dtype(dtype).type)
+        yx = [tuple(s[3:]) for s in shapes]
+        self._dev = [[torch.empty((self.batch,) + s, dtype=tdtype, device=device) for s in yx] for _ in range(slots)]
+        self._host = [[torch.empty((self.batch,) + s, dtype=tdtype, pin_memory=True) for s in yx] for _ in range(slots)]
+        self._free = [threading.Event() for _ in range(slots)]
+        for e in self._free:
+            e.set()
+        self._slot = -1
+        self._m = 0
+        self._error = None
+        self._pool = ThreadPoolExecutor(max_workers=workers if workers is not None else min(32, os.cpu_count() or 4))
+        self._queue: "queue.Queue" = queue.Queue()
+        self._thread = threading.Thread(target=self._dispatch, name='zarr-writer', daemon=True)
+        self._thread.start()
+
+    def _dispatch(self):
+        while True:
+            item = self._queue.get()
+            if item is None:
+                return
+            slot, coords, event = item
+            try:
+                event.synchronize()
+                levels = [h.numpy() for h in self._host[slot]]
+                self.bytes_written += write_plane_levels(self.path, levels, coords, self.chunks, self.compression,
+                                                         self.level, pool=self._pool)
+            except BaseException as exc:   # surfaced by the next acquire() / close()
+                self._error = exc
+            finally:
+                self._free[slot].set()
+
+    def _check(self):
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def acquire(self, m: int):
+        """Device canvas [m, Hc, Wc] of the next slot (contents undefined)."""
+        if not 0 < m <= self.batch:
+            raise ValueError(f"a slot holds 1..{self.batch} planes, asked for {m}")
+        self._slot = (self._slot + 1) % len(self._dev)
+        self._free[self._slot].wait()
+        self._check()
+        self._m = m
+        return self._dev[self._slot][0][:m]
+
+    def submit(self, coords: Sequence[tuple]) -> None:
+        """The canvas handed out by the last ``acquire`` is (being) filled on the current stream."""
+        import torch
+        slot, m = self._slot, self._m
+        if len(coords) != m:
+            raise ValueError(f"{m} planes acquired, {len(coords)} coordinates given")
+        dev = self._dev[slot]
+        device_levels(dev[0][:m], len(dev), out=dev[1:])
+        for d, h in zip(dev, self._host[slot]):
+            h[:m].copy_(d[:m], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._free[slot].clear()
+        self._queue.put((slot, list(coords), event))
+
+    def close(self):
+        for e in self._free:
+            e.wait()
+        self._queue.put(None)
+        self._thread.join()
+        self._pool.shutdown(wait=True)
+        self._check()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -54,7 +54,7 @@ class Signal:
 
 class Stitcher:
     def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
-                 normalization: Optional[str] = 'phase'):
+                 normalization: Optional[str] = 'phase', zarr_compression: str = 'zlib'):
         self.update_progress = Signal(int, int)
         self.getting_flatfields = Signal()
         self.starting_stitching = Signal()
@@ -81,6 +81,10 @@ class Stitcher:
             raise ValueError("fusion_mode must be 'overwrite' or 'feather'")
         self.fusion_mode = fusion_mode            # 'feather' is an extension the reference lacks
         self.normalization = normalization        # scikit-image >= 0.19 default is 'phase'
+        if zarr_compression not in ('zlib', 'none'):
+            raise ValueError("zarr_compression must be 'zlib' or 'none'")
+        self.zarr_compression = zarr_compression
+        self.batch_bytes_limit = 4 << 30          # tile bytes staged (pinned + device) per ingest batch
         self._device = device
         self._plan_cache: Dict[tuple, native.FusePlan] = {}
         self.init_stitching_parameters()
@@ -512,10 +516,14 @@ class Stitcher:
         canvas = planes.view(1, self.num_c, self.num_z, planes.shape[-2], planes.shape[-1])
         return canvas if device_output else canvas.cpu().numpy()
 
-    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None):
+    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None):
         """Fuse the (channel, z) planes ``only_planes`` (plane = channel * num_z + z; None = all) of one
         (timepoint, region) -> (device tensor [n, Hc, Wc], sorted plane ids).  Planes are independent,
-        which is what lets several GPUs share one region."""
+        which is what lets several GPUs share one region.
+
+        ``stream_to``: callable ``batch -> omezarr.PlaneStreamWriter``.  When given, no region-sized canvas
+        is allocated: every batch of planes is fused into one of the writer's two slots and leaves
+        for disk while the next batch is read and fused; the return value is (None, plane ids)."""
         import torch
         start_time = time.time()
         region_data = self.get_region_data(int(timepoint), region)
@@ -527,8 +535,8 @@ class Stitcher:
         slot_of = {p: i for i, p in enumerate(plane_ids)}
         print(f"region {region} timepoint {timepoint} output array dimensions: "
               f"{(1, self.num_c, self.num_z, height, width)}" + ("" if only_planes is None else f", planes {plane_ids}"))
-        flat_canvas = torch.empty((len(plane_ids), height, width), dtype=native.torch_dtype_of(self.dtype),
-                                  device=self.device)
+        flat_canvas = None if stream_to is not None else \
+            torch.empty((len(plane_ids), height, width), dtype=native.torch_dtype_of(self.dtype), device=self.device)
         hc, wc = height, width
         th, tw = self.input_height, self.input_width
         total_tiles = len(region_data)
@@ -551,7 +559,7 @@ class Stitcher:
 
         mode = native.SQ_FUSE_OVERWRITE if self.fusion_mode == 'overwrite' else native.SQ_FUSE_FEATHER
         # planes no file touches still have to come out as zeros
-        empty = [p for p in plane_ids if p not in planes]
+        empty = [p for p in plane_ids if p not in planes] if stream_to is None else []   # streamed: fill_value
         if empty:
             zplan = self._plan_for(np.zeros((0, 6)), th, tw, hc, wc, native.SQ_FUSE_OVERWRITE)
             for p in empty:
@@ -578,10 +586,14 @@ class Stitcher:
             host_free = psutil.virtual_memory().available
         except Exception:   # pragma: no cover
             host_free = 8 << 30
-        budget = max(1, min(int(free_bytes * 0.2), int(host_free * 0.1), 4 << 30))
+        budget = max(1, min(int(free_bytes * 0.2), int(host_free * 0.1), int(self.batch_bytes_limit)))
         tdtype = native.torch_dtype_of(self.dtype)
         processed = 0
         pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
+        writer = None
+        if stream_to is not None and groups:
+            widest = max(len(rect_of[sig]) for sig in groups) * th * tw * np.dtype(self.dtype).itemsize
+            writer = stream_to(max(1, min(max(len(pl) for pl in groups.values()), budget // max(1, widest))))
         try:
             for sig, plist in groups.items():
                 rects = rect_of[sig]
@@ -589,6 +601,8 @@ class Stitcher:
                 plan = self._plan_for(rects, th, tw, hc, wc, mode)
                 per_plane = n * th * tw * np.dtype(self.dtype).itemsize
                 batch = max(1, min(len(plist), budget // max(1, per_plane)))
+                if writer is not None:
+                    batch = min(batch, writer.batch)
                 chunks = [plist[b0:b0 + batch] for b0 in range(0, len(plist), batch)]
                 n_slots = min(2, len(chunks))
                 staging = [torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)]
@@ -621,7 +635,10 @@ class Stitcher:
                     tiles.copy_(staging[slot][:m], non_blocking=True)
                     flats = [flats_dev.get(p // self.num_z) for p in chunk] if self.apply_flatfield else None
                     slots = [slot_of[p] for p in chunk]
-                    if all(slots[i] + 1 == slots[i + 1] for i in range(m - 1)):
+                    if writer is not None:
+                        native.fuse_planes(plan, tiles, writer.acquire(m), flats)
+                        writer.submit([(0, p // self.num_z, p % self.num_z) for p in chunk])
+                    elif all(slots[i] + 1 == slots[i + 1] for i in range(m - 1)):
                         native.fuse_planes(plan, tiles, flat_canvas[slots[0]:slots[0] + m], flats)
                     else:
                         for pi, sl in enumerate(slots):
@@ -631,22 +648,63 @@ class Stitcher:
                     done[slot].record()
         finally:
             pool.shutdown(wait=True)
+            if writer is not None:
+                writer.close()
         torch.cuda.synchronize(self.device)
         print(f"Time to stitch region {region} timepoint {timepoint}: {time.time() - start_time}")
         return flat_canvas, plane_ids
 
     # ------------------------------------------------------------------ output
+    def _zarr_path(self, timepoint, region) -> str:
+        return os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched.ome.zarr")
+
+    def _dz_um(self) -> float:
+        return float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
+
     def save_region_ome_zarr(self, timepoint, region, stitched_region):
-        """(stitcher.py:771-859) via the package-free writer in omezarr.py."""
-        if hasattr(stitched_region, 'cpu'):
-            stitched_region = stitched_region.cpu().numpy()
-        output_path = os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched.ome.zarr")
+        """(stitcher.py:771-859) via the package-free writer in omezarr.py; ``stitched_region`` is a
+        5-D numpy array or device tensor.  The pyramid levels (Scaler.nearest, :797-798) come from the
+        device kernel either way."""
+        output_path = self._zarr_path(timepoint, region)
         os.makedirs(os.path.dirname(output_path), exist_ok=True)
-        dz_um = float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
-        write_ome_zarr(output_path, np.asarray(stitched_region), pixel_size_um=self.pixel_size_um, dz_um=dz_um,
+        write_ome_zarr(output_path, stitched_region, pixel_size_um=self.pixel_size_um, dz_um=self._dz_um(),
                        channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
                        num_levels=self.num_pyramid_levels, chunks=self.chunks or (1, 1, 1, 512, 512),
-                       name=f"{region}_t{timepoint}")
+                       name=f"{region}_t{timepoint}", compression=self.zarr_compression, device=self.device)
+        return output_path
+
+    def create_region_store(self, timepoint, region):
+        """Metadata of the region's OME-Zarr store (no chunks) -> (path, level shapes)."""
+        output_path = self._zarr_path(timepoint, region)
+        os.makedirs(os.path.dirname(output_path), exist_ok=True)
+        width, height = self.calculate_output_dimensions(timepoint, region)
+        shapes = omezarr.create_store(output_path, (1, self.num_c, self.num_z, height, width), self.dtype,
+                                      pixel_size_um=self.pixel_size_um, dz_um=self._dz_um(),
+                                      channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
+                                      num_levels=self.num_pyramid_levels, chunks=self.chunks or (1, 1, 1, 512, 512),
+                                      name=f"{region}_t{timepoint}", compression=self.zarr_compression)
+        return output_path, shapes
+
+    def stream_region_to_zarr(self, timepoint, region, only_planes=None, progress_callback=None, create: bool = True):
+        """stitch_region + save_region_ome_zarr without the region ever existing in one piece: planes
+        are fused a batch at a time and stream through pyramid kernel, pinned D2H copy and compression
+        threads while the next batch is read and fused.  Same store as
+        ``save_region_ome_zarr(t, r, stitch_region(t, r))``."""
+        if create:
+            output_path, shapes = self.create_region_store(timepoint, region)
+        else:
+            output_path = self._zarr_path(timepoint, region)
+            width, height = self.calculate_output_dimensions(timepoint, region)
+            shapes = omezarr.level_shapes((1, self.num_c, self.num_z, height, width), self.num_pyramid_levels)
+        made = []
+
+        def make_writer(batch):
+            made.append(omezarr.PlaneStreamWriter(output_path, shapes, self.dtype, chunks=self.chunks or (1, 1, 1, 512, 512),
+                                                  batch=batch, compression=self.zarr_compression, device=self.device))
+            return made[-1]
+
+        _, ids = self.stitch_planes(timepoint, region, only_planes, progress_callback, stream_to=make_writer)
+        self.last_bytes_written = sum(w.bytes_written for w in made)
         return output_path
 
     def _run_region_by_planes(self, timepoint, region, rank, world):
@@ -654,21 +712,13 @@ class Stitcher:
         an OME-Zarr store never span planes, so the ranks write into one store without locking."""
         mine = sharding.block_cyclic(self.num_c * self.num_z, rank, world)
         print(f"\nProcessing timepoint {timepoint}, region {region}: planes {mine} (rank {rank}/{world})")
-        self.starting_stitching.emit()
-        planes, ids = self.stitch_planes(timepoint, region, mine, progress_callback=self.update_progress.emit)
-        output_path = os.path.join(self.output_folder, f"{timepoint}_stitched", f"{region}_stitched.ome.zarr")
-        shape = (1, self.num_c, self.num_z, int(planes.shape[-2]), int(planes.shape[-1]))
-        dz_um = float(self.acquisition_params.get('dz(um)', 1.0)) if self.acquisition_params else 1.0
-        chunks = self.chunks or (1, 1, 1, 512, 512)
         if rank == 0:
-            os.makedirs(os.path.dirname(output_path), exist_ok=True)
-            omezarr.create_store(output_path, shape, self.dtype, pixel_size_um=self.pixel_size_um, dz_um=dz_um,
-                                 channel_names=self.monochrome_channels, channel_colors=self.monochrome_colors,
-                                 num_levels=self.num_pyramid_levels, chunks=chunks, name=f"{region}_t{timepoint}")
+            self.create_region_store(timepoint, region)
         sharding.barrier()
+        self.starting_stitching.emit()
         self.starting_saving.emit(False)
-        coords = [(0, p // self.num_z, p % self.num_z) for p in ids]
-        omezarr.write_planes(output_path, planes.cpu().numpy(), coords, num_levels=self.num_pyramid_levels, chunks=chunks)
+        output_path = self.stream_region_to_zarr(timepoint, region, mine, progress_callback=self.update_progress.emit,
+                                                 create=False)
         sharding.barrier()
         return output_path
 
@@ -750,11 +800,13 @@ class Stitcher:
             print(f"\nProcessing timepoint {timepoint}, region {region}" + (f" (rank {rank}/{world})" if world > 1 else ""))
             os.makedirs(os.path.join(self.output_folder, f"{timepoint}_stitched"), exist_ok=True)
             self.starting_stitching.emit()
-            stitched_region = self.stitch_region(timepoint, region, progress_callback=self.update_progress.emit)
-            self.starting_saving.emit(False)
             if self.output_format.endswith('.zarr'):
-                output_path = self.save_region_ome_zarr(timepoint, region, stitched_region)
+                # fused planes stream to the store batch by batch; saving overlaps stitching
+                self.starting_saving.emit(False)
+                output_path = self.stream_region_to_zarr(timepoint, region, progress_callback=self.update_progress.emit)
             else:
+                stitched_region = self.stitch_region(timepoint, region, progress_callback=self.update_progress.emit)
+                self.starting_saving.emit(False)
                 output_path = self.save_region_aics(timepoint, region, stitched_region)
             print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
         sharding.barrier()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Command line of the stitcher: the reference's flags (stitcher_cli.py:14-62) unchanged,
-plus two switches for what this build adds (``--fusion-mode``, ``--normalization``).
+plus three switches for what this build adds (``--fusion-mode``, ``--normalization``,
+``--zarr-compression``).
 
     python -m image_stitcher_amd.stitcher_cli -i /path/to/acquisition -r -ff --registration-channel "488"
 """
@@ -29,6 +30,8 @@ FLAGS = (
                               help="overwrite = the reference's last-writer-wins; feather = distance-weighted blend (extension)")),
     (('--normalization',), dict(choices=['phase', 'none'], default='phase',
                                 help="cross-power normalisation: phase = scikit-image >= 0.19 default, none = 0.18 behaviour")),
+    (('--zarr-compression',), dict(choices=['zlib', 'none'], default='zlib',
+                                   help="OME-Zarr chunk compressor (none = raw chunks)")),
 )
 
 
@@ -77,7 +80,8 @@ def main(argv=None):
         device = init_distributed()
         params = create_params(args)
         stitcher = Stitcher(params, device=device, fusion_mode=args.fusion_mode,
-                            normalization=None if args.normalization == 'none' else 'phase')
+                            normalization=None if args.normalization == 'none' else 'phase',
+                            zarr_compression=args.zarr_compression)
         print("Starting stitching with parameters:")
         for k, v in params.to_dict().items():
             print(f"{k}: {v}")

@@ -119,6 +119,18 @@ int64_t sq_fuse_scratch_bytes(int32_t n_planes);
 int sq_fuse_planes(const sq_fuse_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Pyramid: one level of the OME-Zarr multiscale image from the level before.  Replaces
+ * ome_zarr.scale.Scaler(max_layer=n-1).nearest(stitched_region) at stitcher.py:797-798 (level
+ * count: stitcher.py:346-352), i.e. skimage.transform.resize(plane, (Y//2, X//2), order=0,
+ * preserve_range=True, anti_aliasing=False) per plane and level:
+ *     dst[p][y][x] = src[p][2*y + 1][2*x + 1],   dst is (src_h / 2) x (src_w / 2), floor.
+ * Strides and pitches in elements; dtype SQ_U8 or SQ_U16; src and dst must not overlap.
+ * ---------------------------------------------------------------------------------------- */
+int sq_downsample2(const void *src_dev, int64_t src_plane_stride, int32_t src_h, int32_t src_w, int64_t src_pitch,
+                   void *dst_dev, int64_t dst_plane_stride, int64_t dst_pitch, int32_t n_planes, int32_t dtype,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Registration: replaces normalize_image (stitcher.py:613-617), the crops of
  * calculate_horizontal_shift / calculate_vertical_shift (:504-506, :517-519) and
  * skimage.registration.phase_cross_correlation(upsample_factor=10) (:510, :523), batched

@@ -482,3 +482,28 @@ def fuse_plane_feather(tiles, rects: np.ndarray, canvas_h: int, canvas_w: int,
         info = np.iinfo(out_dtype)
         return np.clip(np.rint(out), info.min, info.max).astype(out_dtype)
     return out
+
+
+# --------------------------------------------------------------------------- pyramid (8f row 2)
+def pyramid_nearest(image: np.ndarray, num_levels: int) -> List[np.ndarray]:
+    """The multiscale levels the reference stores: ``ome_zarr.scale.Scaler(max_layer=num_levels - 1)
+    .nearest(image)`` (stitcher.py:797-798).  ome_zarr is a third-party dependency absent from
+    /root/reference and from this image (unpinned in install_requirements.sh:55); its published
+    algorithm: each level is, plane by plane over the last two axes,
+    ``skimage.transform.resize(plane, (Y // 2, X // 2), order=0, preserve_range=True,
+    anti_aliasing=False).astype(dtype)`` of the level before.  Order-0 resize samples source coordinate
+    ``(o + 0.5) * in / out - 0.5`` rounded half up; with ``out = in // 2`` that is index ``2 * o + 1``
+    for every o, even or odd ``in`` (the fractional part lies in [1/(2 out), 1 - 1/(2 out)], never on a
+    tie for odd sizes; exactly on the tie .5 -> rounds up for even sizes).
+
+    Pinned by tests/golden/pyramid_vectors.npz: scikit-image 0.18.3's resize (odd sizes; for an exactly
+    halved dimension 0.18.3 resolves the tie by rounding noise, which is not a behaviour to reproduce)
+    and scipy.ndimage.zoom(order=0, grid_mode=True), the path scikit-image >= 0.19 takes (all sizes)."""
+    levels = [np.asarray(image)]
+    for _ in range(1, max(1, int(num_levels))):
+        prev = levels[-1]
+        y, x = prev.shape[-2:]
+        if y < 2 or x < 2:
+            break
+        levels.append(np.ascontiguousarray(prev[..., 1::2, 1::2][..., :y // 2, :x // 2]))
+    return levels

@@ -260,7 +260,39 @@ def normalize_vectors():
     print('[golden] normalize vectors written')
 
 
+def pyramid_vectors():
+    """What ome_zarr's Scaler.nearest computes per plane and level (stitcher.py:797-798; ome_zarr itself is
+    absent offline): skimage.transform.resize(plane, (Y//2, X//2), order=0, preserve_range=True,
+    anti_aliasing=False).  Two third-party executions are recorded:
+      * ``sk_*``: that call through scikit-image 0.18.3 (here), for sizes with an odd dimension.  For an
+        exactly halved (even) dimension 0.18.3's warp lands on the tie 2*o + 0.5 and resolves it by
+        rounding noise (neither [0::2] nor [1::2]); the recorded ``sk_even_*`` vector shows that, it is not
+        a parity target;
+      * ``zoom_*``: scipy.ndimage.zoom(plane, out/in, order=0, mode='mirror', grid_mode=True), the code
+        path scikit-image >= 0.19 takes for the same resize call; even and odd sizes."""
+    from scipy import ndimage as ndi
+    from skimage.transform import resize
+    rng = np.random.default_rng(77)
+    arrays = {}
+    for i, (shape, dt) in enumerate([((37, 91), 'uint16'), ((513, 255), 'uint16'), ((5, 3), 'uint8'),
+                                     ((101, 77), 'uint8'), ((64, 96), 'uint16'), ((130, 57), 'uint16'),
+                                     ((2, 2), 'uint16'), ((3, 2), 'uint8')]):
+        a = rng.integers(0, np.iinfo(dt).max + 1, shape).astype(dt)
+        out_shape = (shape[0] // 2, shape[1] // 2)
+        arrays[f'in_{i}'] = a
+        sk = resize(a, output_shape=out_shape, order=0, preserve_range=True, anti_aliasing=False).astype(a.dtype)
+        both_odd_or_tiny = all(n % 2 == 1 for n in shape)
+        arrays[('sk_' if both_odd_or_tiny else 'sk_even_') + str(i)] = sk
+        arrays[f'zoom_{i}'] = ndi.zoom(a, [o / n for o, n in zip(out_shape, shape)], order=0, mode='mirror',
+                                       grid_mode=True)
+        assert arrays[f'zoom_{i}'].shape == out_shape
+    np.savez_compressed(os.path.join(HERE, 'pyramid_vectors.npz'), **arrays)
+    print('[golden] pyramid vectors written')
+
+
 def main():
+    if sys.argv[1:] == ['pyramid']:
+        return pyramid_vectors()
     G = synth.GridSpec
     ch2 = synth.DEFAULT_CHANNELS[:2]
     # config 1: 2x2 of 512^2, coordinate-only (BASELINE.json configs[0])
@@ -307,6 +339,7 @@ def main():
     pcc_vectors()
     flatfield_vectors()
     normalize_vectors()
+    pyramid_vectors()
 
 
 if __name__ == '__main__':

@@ -56,19 +56,43 @@ def test_tiff_roundtrip(tmp_path):
 
 
 def test_omezarr_roundtrip(tmp_path):
+    """Store layout and chunk writing; the pyramid levels are inputs here (the product computes them on
+    the device, the oracle stands in for it on CPU)."""
+    from oracle import stitch_oracle as O
     rng = np.random.default_rng(1)
-    img = rng.integers(0, 65536, (1, 2, 3, 700, 530)).astype(np.uint16)
+    img = rng.integers(0, 65536, (1, 2, 3, 701, 530)).astype(np.uint16)
     img[0, 1, 2] = 0    # an all-zero plane is not written (fill_value)
-    path = omezarr.write_ome_zarr(str(tmp_path / 'r.ome.zarr'), img, pixel_size_um=0.5, dz_um=1.5,
-                                  channel_names=['a 405', 'b 488'], channel_colors=[0xFF, 0xFF00], num_levels=3)
+    levels = O.pyramid_nearest(img, 3)
+    for compression in ('zlib', 'none'):
+        path = str(tmp_path / f'r_{compression}.ome.zarr')
+        shapes = omezarr.create_store(path, img.shape, img.dtype, pixel_size_um=0.5, dz_um=1.5,
+                                      channel_names=['a 405', 'b 488'], channel_colors=[0xFF, 0xFF00], num_levels=3,
+                                      compression=compression)
+        assert shapes == [lv.shape for lv in levels] == [(1, 2, 3, 701, 530), (1, 2, 3, 350, 265), (1, 2, 3, 175, 132)]
+        coords = [(0, c, z) for c in range(2) for z in range(3)]
+        # two "processes" write different planes of the same store
+        for part in (slice(0, 4), slice(4, 6)):
+            n = omezarr.write_plane_levels(path, [lv.reshape((-1,) + lv.shape[3:])[part] for lv in levels], coords[part],
+                                           compression=compression)
+            assert n > 0
+        for lv in range(3):
+            np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, str(lv))), levels[lv])
+        assert not os.path.exists(os.path.join(path, '0', '0', '1', '2'))
+        with open(os.path.join(path, '.zattrs')) as fh:
+            attrs = json.load(fh)
+        ms = attrs['multiscales'][0]
+        assert [a['name'] for a in ms['axes']] == ['t', 'c', 'z', 'y', 'x']
+        assert ms['datasets'][2]['coordinateTransformations'][0]['scale'] == [1, 1, 1.5, 2.0, 2.0]
+        assert [c['label'] for c in attrs['omero']['channels']] == ['a 405', 'b 488']
+    # single-level numpy input needs no GPU; a pyramid of a numpy input does (no host decimation exists)
+    path = omezarr.write_ome_zarr(str(tmp_path / 'one.ome.zarr'), img, pixel_size_um=0.5, num_levels=1)
     np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '0')), img)
-    np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, '1')), img[..., ::2, ::2])
-    with open(os.path.join(path, '.zattrs')) as fh:
-        attrs = json.load(fh)
-    ms = attrs['multiscales'][0]
-    assert [a['name'] for a in ms['axes']] == ['t', 'c', 'z', 'y', 'x']
-    assert ms['datasets'][2]['coordinateTransformations'][0]['scale'] == [1, 1, 1.5, 2.0, 2.0]
-    assert [c['label'] for c in attrs['omero']['channels']] == ['a 405', 'b 488']
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            omezarr.write_ome_zarr(str(tmp_path / 'two.ome.zarr'), img, pixel_size_um=0.5, num_levels=2)
+    with pytest.raises(ValueError):
+        omezarr.create_store(str(tmp_path / 'bad.ome.zarr'), img.shape, img.dtype, pixel_size_um=1.0, compression='lz4')
 
 
 def test_ometiff_roundtrip(tmp_path):

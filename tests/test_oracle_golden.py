@@ -129,3 +129,39 @@ def test_region_case(name, tmp_path):
             np.testing.assert_array_equal(canvas, arrays[f'{key}_canvas'])
         for wi, (c, z, y0, x0, hh, ww) in enumerate(cinfo.get('windows', [])):
             np.testing.assert_array_equal(canvas[0, c, z, y0:y0 + hh, x0:x0 + ww], arrays[f'{key}_win{wi}'])
+
+
+def test_pyramid_nearest_golden():
+    """The pyramid restatement against third-party executions of the resize Scaler.nearest performs
+    (make_golden.pyramid_vectors): scikit-image 0.18.3 for odd sizes, scipy's grid-mode zoom (the
+    scikit-image >= 0.19 path) for all sizes."""
+    v = np.load(os.path.join(GOLDEN, 'pyramid_vectors.npz'))
+    n_sk = n_zoom = 0
+    for key in v.files:
+        if not key.startswith('in_'):
+            continue
+        i = key[3:]
+        got = O.pyramid_nearest(v[key], 2)[1]
+        np.testing.assert_array_equal(got, v[f'zoom_{i}'])
+        n_zoom += 1
+        if f'sk_{i}' in v.files:
+            np.testing.assert_array_equal(got, v[f'sk_{i}'])
+            n_sk += 1
+    assert n_zoom >= 8 and n_sk >= 3
+
+
+def test_pyramid_nearest_matches_live_scipy_zoom():
+    """Same check against the scipy of this interpreter, on more sizes, over several levels."""
+    ndi = pytest.importorskip('scipy.ndimage')
+    rng = np.random.default_rng(5)
+    for shape in [(2, 301, 212), (1, 64, 64), (3, 17, 255), (1, 1, 9), (1, 9, 1)]:
+        img = rng.integers(0, 65536, shape).astype(np.uint16)
+        levels = O.pyramid_nearest(img, 5)
+        for lv in range(1, len(levels)):
+            prev = levels[lv - 1]
+            oy, ox = prev.shape[-2] // 2, prev.shape[-1] // 2
+            assert levels[lv].shape == prev.shape[:-2] + (oy, ox)
+            for pl in range(shape[0]):
+                want = ndi.zoom(prev[pl], (oy / prev.shape[-2], ox / prev.shape[-1]), order=0, mode='mirror', grid_mode=True)
+                np.testing.assert_array_equal(levels[lv][pl], want)
+    assert len(O.pyramid_nearest(np.zeros((1, 1, 9), np.uint8), 5)) == 1       # a size-1 axis ends the pyramid

@@ -70,7 +70,7 @@ def test_library_exports_every_declared_symbol():
     L = native.lib()
     with open(os.path.join(ROOT, 'include', 'squidstitch.h')) as fh:
         hdr = fh.read()
-    declared = set(re.findall(r'\b(sq_[a-z_]+)\s*\(', hdr))
+    declared = set(re.findall(r'\b(sq_[a-z0-9_]+)\s*\(', hdr))
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
