@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--ov', type=int, default=244)
     ap.add_argument('--flat', choices=['none', 'f32', 'f64'], default='none')
     ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--nflats', type=int, default=1, help='distinct flatfields, dealt to planes in blocks (channels)')
     ap.add_argument('--drift', type=int, nargs=2, default=[3, -2])
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -44,7 +45,8 @@ def main():
     flats = None
     if a.flat != 'none':
         ff = torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)).to(dev)
-        flats = [ff] * a.planes
+        ffs = [ff.clone() for _ in range(a.nflats)]
+        flats = [ffs[p * a.nflats // a.planes] for p in range(a.planes)]
     for _ in range(2):
         native.fuse_planes(plan, tiles, canvas, flats)
     torch.cuda.synchronize()
