@@ -92,21 +92,31 @@ __device__ __forceinline__ T flat_f32(T v, float g) {
     return (T)q;
 }
 // Fast exact flatfield divide for THIS operand class: numerator an integer in [0, 65535], gain a
-// float32 with 2^-100 <= |g| < 2^128 (either sign).  Markstein's scheme -- reciprocal refined by one
-// Newton step on v_rcp_f32, one quotient, one exact-residual correction -- gives the correctly
-// rounded quotient here because a 16-bit numerator keeps n/g at least 2^-41 (relative) away from
-// every rounding boundary, far more than the 2^-46 the uncorrected error can reach.  Below 2^-112
-// the first quotient would overflow and the correction turn into inf - inf; the guard leaves a wide
-// margin.  None of this is taken on faith: sq_selftest_flat_divide compares the final clipped
-// integers with the IEEE path for ALL 2^23 mantissas x 65536 numerators in every binade of the
-// range (tests/test_fuse_gpu.py).  Zeros, denormals, tiny gains, infinities and NaNs among a
-// plane's gains are found by a pre-pass (flat_classify_kernel) and send that plane through the
+// float32 with 2^-100 <= |g| < 2^128 (either sign).  Markstein's scheme -- the hardware reciprocal
+// (v_rcp_f32, 1 ulp), one quotient, one exact-residual correction -- gives the correctly rounded
+// quotient here: with r = (1/g)(1 + e), q = n r has relative error h <= |e| + 2^-24, the residual
+// n - g q is exact in one FMA, and q + rem r = (n/g)(1 - h e), i.e. wrong by < 2^-44 relative
+// before its single rounding, while a 16-bit numerator keeps n/g at least 2^-41 (relative) away
+// from every rounding boundary.  A Newton step on r (two more FMAs) is therefore not needed; it was
+// there in earlier versions and is kept behind SQ_DIV_NEWTON.  Below 2^-112 the first quotient
+// would overflow and the correction turn into inf - inf; the guard leaves a wide margin.  None of
+// this is taken on faith: sq_selftest_flat_divide compares the final clipped integers with the
+// IEEE path for ALL 2^23 mantissas x 65536 numerators in every binade of the range, on the GPU the
+// tests run on (tests/test_fuse_gpu.py).  Zeros, denormals, tiny gains, infinities and NaNs among
+// a plane's gains are found by a pre-pass (flat_classify_kernel) and send that plane through the
 // generic IEEE sequence instead.
-// Saves the two v_div_scale, v_div_fmas, v_div_fixup and the second refinement (11 -> 6 VALU slots).
+// 4 VALU slots + the reciprocal instead of the 11 of the IEEE sequence (two v_div_scale, v_div_fmas,
+// v_div_fixup, two refinements).  Doing two pixels per instruction on the packed-float32 pipe
+// (v_pk_mul_f32 / v_pk_fma_f32) was tried: it needs 86 VGPRs (5 waves) and measured no faster.
+#ifndef SQ_DIV_NEWTON
+#define SQ_DIV_NEWTON 0
+#endif
 __device__ __forceinline__ float div_u16_normal(float n, float g) {
     float r = __builtin_amdgcn_rcpf(g);
+#if SQ_DIV_NEWTON
     const float e = fmaf(-g, r, 1.0f);
     r = fmaf(e, r, r);
+#endif
     const float q = n * r;
     const float rem = fmaf(-g, q, n);
     return fmaf(rem, r, q);
