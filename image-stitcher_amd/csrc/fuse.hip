@@ -84,15 +84,18 @@ __device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int
 // divide -> clip -> truncating cast of apply_flatfield_correction (stitcher.py:609-610), in the
 // flatfield's own precision like numpy's uint16 / floatXX promotion.  NaN (0/0) -> 0, which is
 // what the x86 cast of the reference produces; +inf -> dtype max through the clip.
-template <typename T>
+// RND = 0: truncate (the reference's astype).  RND = 1: round half to even first -- feather mode's
+// integer output (np.rint) for a voxel a single tile covers.
+template <typename T, int RND = 0>
 __device__ __forceinline__ T flat_f32(T v, float g) {
     float q = __fdiv_rn((float)v, g);
+    if (RND) q = rintf(q);
     const float hi = sizeof(T) == 1 ? 255.0f : 65535.0f;
     q = fminf(fmaxf(q, 0.0f), hi);
     return (T)q;
 }
 // Fast exact flatfield divide for THIS operand class: numerator an integer in [0, 65535], gain a
-// float32 with 2^-100 <= |g| < 2^128 (either sign).  Markstein's scheme -- the hardware reciprocal
+// float32 with 2^-100 <= |g| < 2^100 (either sign).  Markstein's scheme -- the hardware reciprocal
 // (v_rcp_f32, 1 ulp), one quotient, one exact-residual correction -- gives the correctly rounded
 // quotient here: with r = (1/g)(1 + e), q = n r has relative error h <= |e| + 2^-24, the residual
 // n - g q is exact in one FMA, and q + rem r = (n/g)(1 - h e), i.e. wrong by < 2^-44 relative
@@ -121,7 +124,8 @@ __device__ __forceinline__ float div_u16_normal(float n, float g) {
     const float rem = fmaf(-g, q, n);
     return fmaf(rem, r, q);
 }
-constexpr int FAST_MIN_EXP = -100;   // fast divide allowed for 2^FAST_MIN_EXP <= |g| < 2^128
+constexpr int FAST_MIN_EXP = -100;   // fast divide allowed for 2^FAST_MIN_EXP <= |g| < 2^FAST_END_EXP:
+constexpr int FAST_END_EXP = 100;    // (every non-zero quotient n/g is then a normal float)
 
 // float -> uint32 the way the hardware does it: negative and NaN -> 0, too large -> 0xFFFFFFFF.
 // (C++'s (uint32_t)f is undefined outside the range, so say the instruction.)
@@ -131,16 +135,33 @@ __device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
     return r;
 }
 
-template <typename T>
+// RND = 1 (feather mode rounds the float32 quotient half to even): the reference's result then hangs
+// on how n/g rounds to float32 right next to a representable k + 0.5, and n/g can be within 2^-48 of
+// that float midpoint -- the short sequence is not enough there (the exhaustive test finds two gain
+// mantissas per binade that fail, e.g. 4075 / 0x1.dbf3fep-3).  This is the full IEEE sequence
+// (Newton step on the reciprocal, quotient, two exact-residual corrections) minus its v_div_scale /
+// v_div_fmas / v_div_fixup range handling, which this operand class never needs: 8 slots, not 11.
+template <int RND>
+__device__ __forceinline__ float quotient_u16_normal(float n, float g) {
+    if (!RND) return div_u16_normal(n, g);
+    float r = __builtin_amdgcn_rcpf(g);
+    r = fmaf(fmaf(-g, r, 1.0f), r, r);
+    float q = n * r;
+    q = fmaf(fmaf(-g, q, n), r, q);
+    q = fmaf(fmaf(-g, q, n), r, q);
+    return __builtin_rintf(q);   // v_rndne_f32
+}
+template <typename T, int RND = 0>
 __device__ __forceinline__ T flat_f32_fast(T v, float g) {
     // clip(q, 0, max) then truncate == saturating conversions: NaN never occurs on this path
-    const uint32_t k = cvt_u32_sat(div_u16_normal((float)v, g));
+    const uint32_t k = cvt_u32_sat(quotient_u16_normal<RND>((float)v, g));
     return (T)min(k, sizeof(T) == 1 ? 255u : 65535u);
 }
 // two pixels of one 32-bit word at once: v_cvt_pk_u16_u32 saturates to 65535 and packs
+template <int RND = 0>
 __device__ __forceinline__ uint32_t flat_f32_fast_pair(uint32_t word, float g_lo, float g_hi) {
-    const uint32_t a = cvt_u32_sat(div_u16_normal((float)(word & 0xFFFFu), g_lo));
-    const uint32_t b = cvt_u32_sat(div_u16_normal((float)(word >> 16), g_hi));
+    const uint32_t a = cvt_u32_sat(quotient_u16_normal<RND>((float)(word & 0xFFFFu), g_lo));
+    const uint32_t b = cvt_u32_sat(quotient_u16_normal<RND>((float)(word >> 16), g_hi));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
@@ -262,7 +283,7 @@ __device__ __forceinline__ void slot_load(Slot<T, FLAT> &S, const Row<T> &J, int
 }
 
 // non-temporal stores: the canvas is written once and never read back by this kernel
-template <typename T, int FLAT, bool FAST>
+template <typename T, int FLAT, bool FAST, int RND>
 __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, int lane, int k) {
     constexpr int VEC = Pix<T>::N;
     const int v = lane + 64 * k;
@@ -272,21 +293,21 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
             if (FAST && sizeof(T) == 2) {   // every gain of this plane is inside the fast range (pre-pass flag)
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q) {
-                    px[2 * q] = flat_f32_fast_pair(px[2 * q], S.g32[q][0], S.g32[q][1]);
-                    px[2 * q + 1] = flat_f32_fast_pair(px[2 * q + 1], S.g32[q][2], S.g32[q][3]);
+                    px[2 * q] = flat_f32_fast_pair<RND>(px[2 * q], S.g32[q][0], S.g32[q][1]);
+                    px[2 * q + 1] = flat_f32_fast_pair<RND>(px[2 * q + 1], S.g32[q][2], S.g32[q][3]);
                 }
             } else if (FAST) {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        Pix<T>::set(px, 4 * q + e, flat_f32_fast<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+                        Pix<T>::set(px, 4 * q + e, flat_f32_fast<T, RND>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
             } else {
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        Pix<T>::set(px, 4 * q + e, flat_f32<T>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
+                        Pix<T>::set(px, 4 * q + e, flat_f32<T, RND>(Pix<T>::get(px, 4 * q + e), S.g32[q][e]));
             }
         } else if (FLAT == 2 && J.frow) {
 #pragma unroll
@@ -299,7 +320,7 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
     }
     if (k == 0 && J.edge_p >= 0) {
         T t = S.edge;
-        if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T>(t, S.eg32) : flat_f32<T>(t, S.eg32);
+        if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T, RND>(t, S.eg32) : flat_f32<T, RND>(t, S.eg32);
         if (FLAT == 2 && J.frow) t = flat_f64<T>(t, S.eg64);
         stg_s<T>(J.drow + J.edge_p, t);
     }
@@ -332,7 +353,7 @@ __device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
 #endif
 
 // the software pipeline over the (row, slot) steps of RB rows (see the comment above Row)
-template <typename T, int FLAT, bool FAST, int RB, int SLOTS, int DEPTH>
+template <typename T, int FLAT, bool FAST, int RND, int RB, int SLOTS, int DEPTH>
 __device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
     constexpr int NSTEP = RB * SLOTS;
     Slot<T, FLAT> buf[DEPTH + 1];
@@ -341,7 +362,7 @@ __device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
         if (s < NSTEP) slot_load<T, FLAT>(buf[s % (DEPTH + 1)], J[s / SLOTS], lane, s % SLOTS);
         if (s >= DEPTH) {
             const int d = s - DEPTH;
-            slot_store<T, FLAT, FAST>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
+            slot_store<T, FLAT, FAST, RND>(buf[d % (DEPTH + 1)], J[d / SLOTS], lane, d % SLOTS);
         }
     }
 }
@@ -357,7 +378,7 @@ __device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
 #ifndef SQ_WAVES_F64
 #define SQ_WAVES_F64 1
 #endif
-template <typename T, int FLAT>
+template <typename T, int FLAT, int RND = 0>
 __device__ __forceinline__ void process_item(const FuseParams &P, int plane, const Item &it, const T *tile, int wave,
                                              int lane) {
     constexpr int VEC = Pix<T>::N;
@@ -390,8 +411,8 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
             J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
             row_setup<T>(J[j], lane);
         }
-        if (fast) pipeline_rows<T, FLAT, true, RB, SLOTS, DEPTH>(J, lane);
-        else pipeline_rows<T, FLAT, false, RB, SLOTS, DEPTH>(J, lane);
+        if (fast) pipeline_rows<T, FLAT, true, RND, RB, SLOTS, DEPTH>(J, lane);
+        else pipeline_rows<T, FLAT, false, RND, RB, SLOTS, DEPTH>(J, lane);
     }
 }
 
@@ -402,7 +423,7 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
 // was fetched exactly once -- but the per-item barrier + atomic cost more than the L2 misses it
 // removed (they are served by the Infinity Cache): 3320 vs 3594 GB/s on the same box.
 template <typename T, int FLAT>
-__global__ __launch_bounds__(256, (FLAT == 1 ? SQ_WAVES_F32 : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
+__global__ __launch_bounds__(256, (FLAT == 1 ? (sizeof(T) == 2 ? SQ_WAVES_F32 : 1) : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
 void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -463,107 +484,190 @@ __device__ __forceinline__ OutT feather_out(float o) {
     return (OutT)fminf(fmaxf(rintf(o), 0.0f), hi);
 }
 
+// One 8-pixel group (p0 .. p0+7 of item row r) blended from the item's references.  The loads of up
+// to four references (pixels and gains) are issued before the first use; references are
+// wave-uniform, so the loops over them run on scalar registers.
 template <typename T, typename OutT, int FLAT>
-__global__ __launch_bounds__(256) void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
-                                                            const int64_t n_work) {
+__device__ __forceinline__ void blend_group(const FuseParams &P, int plane, const Item &it, const char *flat, int r, int p0,
+                                            OutT *dst) {
     constexpr int VEC = 8;
+    constexpr int MAXR = 4;
+    const int nref = it.nref;
+    float acc[VEC], wsum[VEC], last[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = wsum[e] = last[e] = 0.0f;
+    auto blend = [&](const float (&px)[VEC], int y, int x0) {
+        const int wy = min(y + 1, P.tile_h - y);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int x = x0 + e;
+            const float w = (float)min(min(x + 1, P.tile_w - x), wy);
+            acc[e] = __fadd_rn(acc[e], __fmul_rn(w, px[e]));
+            wsum[e] = __fadd_rn(wsum[e], w);
+            last[e] = px[e];
+        }
+    };
+    if (sizeof(T) == 2 && FLAT != 2 && nref <= MAXR) {
+        u32x4 raw[MAXR];
+        f32x4 g[MAXR][2];
+        int ys[MAXR], xs[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < nref) {
+                const Ref rf = P.refs[it.a + k];
+                ys[k] = rf.src_y + it.b + r;
+                xs[k] = rf.src_x + it.c + p0;
+                raw[k] = ldg<U32x4U>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)ys[k] * P.tile_pitch + xs[k]);
+                if (FLAT == 1 && flat) {
+                    const float *gp = reinterpret_cast<const float *>(flat) + (int64_t)ys[k] * P.tile_w + xs[k];
+                    g[k][0] = ldg<F32x4U>(gp);
+                    g[k][1] = ldg<F32x4U>(gp + 4);
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < nref) {
+                float px[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    px[e] = (float)Pix<uint16_t>::get(raw[k], e);
+                    if (FLAT == 1 && flat) px[e] = __fdiv_rn(px[e], g[k][e >> 2][e & 3]);
+                }
+                blend(px, ys[k], xs[k]);
+            }
+    } else {
+        for (int k = 0; k < nref; ++k) {
+            const Ref rf = P.refs[it.a + k];
+            const T *tile = tile_ptr<T>(P, plane, rf.tile);
+            const int y = rf.src_y + it.b + r;
+            const int x0 = rf.src_x + it.c + p0;
+            const T *src = tile + (int64_t)y * P.tile_pitch + x0;
+            float px[VEC];
+            if (sizeof(T) == 2) {
+                const u32x4 raw = ldg<U32x4U>(src);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) px[e] = (float)Pix<uint16_t>::get(raw, e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) px[e] = (float)ldg_s<T>(src + e);
+            }
+            if (FLAT && flat) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const char *gp = flat + ((int64_t)y * P.tile_w + x0 + e) * (FLAT == 2 ? 8 : 4);
+                    const float gain = FLAT == 2 ? (float)ldg_s<double>(gp) : ldg_s<float>(gp);
+                    px[e] = __fdiv_rn(px[e], gain);
+                }
+            }
+            blend(px, y, x0);
+        }
+    }
+    OutT o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = feather_out<OutT>(nref == 1 ? last[e] : (nref ? __fdiv_rn(acc[e], wsum[e]) : 0.0f));
+    if (sizeof(OutT) == 2) {
+        u32x4 out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = (uint32_t)(uint16_t)o[2 * q] | ((uint32_t)(uint16_t)o[2 * q + 1] << 16);
+        stg_nt(dst, out);
+    } else if (sizeof(OutT) == 4) {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lo[q] = __float_as_uint((float)o[q]);
+            hi[q] = __float_as_uint((float)o[4 + q]);
+        }
+        stg_nt(dst, lo);
+        stg_nt(dst + 4, hi);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) stg_s<OutT>(dst + e, o[e]);
+    }
+}
+
+// A blended item: its (row, 8-pixel group) pairs are dealt to the 256 threads of the workgroup, so a
+// narrow overlap strip (244 pixels = 30 groups per row) keeps every lane busy; stores are aligned to
+// the 8-pixel group of the canvas row, the pixels before / after the aligned body go one per thread.
+template <typename T, typename OutT, int FLAT>
+__device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const Item &it, int tid) {
+    constexpr int VEC = 8;
+    const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    const int nref = it.nref;
+    OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
+    const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
+    const int G = n / VEC + 1;   // upper bound of the whole groups of a row
+    for (int idx = tid; idx < rows * G; idx += 256) {
+        const int r = idx / G, j = idx - r * G;
+        OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(OutT)) & (VEC - 1));
+        const int v = (mis ? 1 : 0) + j;
+        if (v >= (n + mis) / VEC) continue;
+        const int p0 = v * VEC - mis;
+        blend_group<T, OutT, FLAT>(P, plane, it, flat, r, p0, drow + p0);
+    }
+    for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
+        const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
+        OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(OutT)) & (VEC - 1));
+        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int p = -1;
+        if (l < VEC) {
+            if (l < head_end) p = l;
+        } else if (tail_start + (l - VEC) < n) {
+            p = tail_start + (l - VEC);
+        }
+        if (p < 0) continue;
+        float acc = 0.0f, wsum = 0.0f, last = 0.0f;
+        for (int k = 0; k < nref; ++k) {
+            const Ref rf = P.refs[it.a + k];
+            const int y = rf.src_y + it.b + r, x = rf.src_x + it.c + p;
+            float v = (float)ldg_s<T>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)y * P.tile_pitch + x);
+            if (FLAT && flat) {
+                const char *gp = flat + ((int64_t)y * P.tile_w + x) * (FLAT == 2 ? 8 : 4);
+                const float gain = FLAT == 2 ? (float)ldg_s<double>(gp) : ldg_s<float>(gp);
+                v = __fdiv_rn(v, gain);
+            }
+            const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
+            acc = __fadd_rn(acc, __fmul_rn(w, v));
+            wsum = __fadd_rn(wsum, w);
+            last = v;
+        }
+        stg_s<OutT>(drow + p, feather_out<OutT>(nref == 1 ? last : (nref ? __fdiv_rn(acc, wsum) : 0.0f)));
+    }
+}
+
+#ifndef SQ_WAVES_FEATHER_F32
+#define SQ_WAVES_FEATHER_F32 5
+#endif
+template <typename T, typename OutT, int FLAT>
+__global__ __launch_bounds__(256, (FLAT == 1 && sizeof(T) == 2 && sizeof(OutT) == 2 ? SQ_WAVES_FEATHER_F32 : 1))
+void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
+                                                            const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
         const int plane = (int)(work / n_items);
         const Item it = P.items[work - plane * n_items];
-        const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
         const int nref = it.nref;
-        OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
-        const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
-        for (int r = wave; r < rows; r += 4) {
-            OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
-            const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(OutT)) & (VEC - 1));
-            const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
-            // ---- whole 8-pixel groups ------------------------------------------------------
-            for (int v = v_first + lane; v < v_end; v += 64) {
-                const int p0 = v * VEC - mis;
-                float acc[VEC], wsum[VEC], last[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] = wsum[e] = last[e] = 0.0f;
-                for (int k = 0; k < nref; ++k) {
-                    const Ref rf = P.refs[it.a + k];
-                    const T *tile = tile_ptr<T>(P, plane, rf.tile);
-                    const int y = rf.src_y + it.b + r;
-                    const int x0 = rf.src_x + it.c + p0;
-                    const T *src = tile + (int64_t)y * P.tile_pitch + x0;
-                    float px[VEC];
-                    if (sizeof(T) == 2) {
-                        const u32x4 raw = ldg<U32x4U>(src);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) px[e] = (float)Pix<uint16_t>::get(raw, e);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) px[e] = (float)ldg_s<T>(src + e);
-                    }
-                    if (FLAT && flat) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const char *g = flat + ((int64_t)y * P.tile_w + x0 + e) * (FLAT == 2 ? 8 : 4);
-                            px[e] = __fdiv_rn(px[e], FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g));
-                        }
-                    }
-                    const int wy = min(y + 1, P.tile_h - y);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        const int x = x0 + e;
-                        const float w = (float)min(min(x + 1, P.tile_w - x), wy);
-                        acc[e] = __fadd_rn(acc[e], __fmul_rn(w, px[e]));
-                        wsum[e] = __fadd_rn(wsum[e], w);
-                        last[e] = px[e];
-                    }
-                }
-                OutT o[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    o[e] = feather_out<OutT>(nref == 1 ? last[e] : (nref ? __fdiv_rn(acc[e], wsum[e]) : 0.0f));
-                if (sizeof(OutT) == 2) {
-                    u32x4 out;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) out[q] = (uint32_t)(uint16_t)o[2 * q] | ((uint32_t)(uint16_t)o[2 * q + 1] << 16);
-                    stg_nt(drow + p0, out);
-                } else if (sizeof(OutT) == 4) {
-                    u32x4 lo, hi;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        lo[q] = __float_as_uint((float)o[q]);
-                        hi[q] = __float_as_uint((float)o[4 + q]);
-                    }
-                    stg_nt(drow + p0, lo);
-                    stg_nt(drow + p0 + 4, hi);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) stg_s<OutT>(drow + p0 + e, o[e]);
-                }
+        if (sizeof(OutT) == sizeof(T) && FLAT != 2 && nref <= 1) {
+            // nothing to blend: uncovered canvas, or one tile -> the overwrite kernel's pipelined copy
+            // (with float32 gains: divide, round half to even, clip -- what the blend yields for a
+            // single reference)
+            Item one = it;
+            const T *tile = nullptr;
+            if (nref) {
+                const Ref rf = P.refs[it.a];
+                tile = tile_ptr<T>(P, plane, rf.tile);
+                one.a = rf.tile;
+                one.b = rf.src_y + it.b;
+                one.c = rf.src_x + it.c;
             }
-            // ---- row edges: one pixel per lane ---------------------------------------------
-            const int head_end = min(n, v_first * VEC - mis);
-            const int tail_start = max(head_end, v_end * VEC - mis);
-            int p = -1;
-            if (lane < VEC) {
-                if (lane < head_end) p = lane;
-            } else if (lane < 2 * VEC) {
-                if (tail_start + (lane - VEC) < n) p = tail_start + (lane - VEC);
-            }
-            if (p >= 0) {
-                float acc = 0.0f, wsum = 0.0f, last = 0.0f;
-                for (int k = 0; k < nref; ++k) {
-                    const Ref rf = P.refs[it.a + k];
-                    const int y = rf.src_y + it.b + r, x = rf.src_x + it.c + p;
-                    const float v = feather_value<T, FLAT>(P, tile_ptr<T>(P, plane, rf.tile), flat, y, x);
-                    const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
-                    acc = __fadd_rn(acc, __fmul_rn(w, v));
-                    wsum = __fadd_rn(wsum, w);
-                    last = v;
-                }
-                stg_s<OutT>(drow + p, feather_out<OutT>(nref == 1 ? last : (nref ? __fdiv_rn(acc, wsum) : 0.0f)));
-            }
+            process_item<T, FLAT == 2 ? 0 : FLAT, 1>(P, plane, one, tile, wave, lane);
+            continue;
         }
+        blend_item<T, OutT, FLAT>(P, plane, it, threadIdx.x);
     }
 }
 
@@ -601,7 +705,7 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     {
         const float g = fabsf(ldg_s<float>(f + i));
-        odd |= !(g >= __builtin_ldexpf(1.0f, FAST_MIN_EXP) && g < __builtin_inff());   // NaN fails both
+        odd |= !(g >= __builtin_ldexpf(1.0f, FAST_MIN_EXP) && g < __builtin_ldexpf(1.0f, FAST_END_EXP));   // NaN fails both
     }
     if (__builtin_amdgcn_ballot_w64(odd) && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], 1u);
 }
@@ -621,6 +725,17 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int
         local += want != flat_f32_fast<uint16_t>((uint16_t)v, g);
         local += want != (pair & 0xFFFFu);
         local += want != (pair >> 16);
+        // rounded instead of truncated (feather mode, voxels one tile covers).  NB the quotient float
+        // itself is NOT always the IEEE one: n/g can sit within 2^-48 of a float midpoint, closer than the
+        // sequence's 2^-46 error, while integer and half-integer boundaries are >= 2^-41 away -- so only
+        // results that end in an integer may use it; the blend of several tiles divides the IEEE way.
+        local += flat_f32<uint16_t, 1>((uint16_t)v, g) != flat_f32_fast<uint16_t, 1>((uint16_t)v, g);
+#ifdef SQ_SELFTEST_DEBUG
+        if (flat_f32<uint16_t, 1>((uint16_t)v, g) != flat_f32_fast<uint16_t, 1>((uint16_t)v, g) && atomicAdd(bad + 1, 1ull) < 8)
+            printf("rint mismatch v=%d g=%a (%08x): ieee q=%a -> %u, fast q=%a -> %u\n", v, g, bits, __fdiv_rn((float)v, g),
+                   (unsigned)flat_f32<uint16_t, 1>((uint16_t)v, g), quotient_u16_normal<1>((float)v, g),
+                   (unsigned)flat_f32_fast<uint16_t, 1>((uint16_t)v, g));
+#endif
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
@@ -630,9 +745,9 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int
 
 extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
                                        void *stream) {
-    if (!mismatches_dev || exponent < FAST_MIN_EXP || n_binades < 1 || exponent + n_binades - 1 > 127)
-        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide: binades [%d, %d] outside the fast path's range [%d, 127]",
-                    exponent, exponent + n_binades - 1, FAST_MIN_EXP);
+    if (!mismatches_dev || exponent < FAST_MIN_EXP || n_binades < 1 || exponent + n_binades > FAST_END_EXP)
+        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide: binades [%d, %d] outside the fast path's range [%d, %d]",
+                    exponent, exponent + n_binades - 1, FAST_MIN_EXP, FAST_END_EXP - 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s);
     if (e == hipSuccess) {
@@ -697,7 +812,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.flat_class = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
-    if (flat == 1 && a->scratch_dev && a->mode == SQ_FUSE_OVERWRITE && a->n_planes > 0) {
+    if (flat == 1 && a->scratch_dev && a->n_planes > 0) {
         // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
         if (a->scratch_bytes < sq_fuse_scratch_bytes(a->n_planes))
             return fail(SQ_ERR_WORKSPACE, "sq_fuse_planes: scratch %lld < %lld bytes", (long long)a->scratch_bytes,

@@ -195,11 +195,11 @@ typedef struct sq_register_args {
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
 
-/* Self-test (tests only): the fusion kernel divides uint16 pixels by float32 gains with a shortened
- * sequence that is exact for gains with 2^-100 <= |g| < 2^128.  This compares its final clipped
- * integers with the IEEE path for ALL 2^23 gain mantissas x all 65536 numerators in n_binades
- * consecutive binades starting at 2^exponent (allowed: -100..127), either sign, and leaves the number
- * of differing results in *mismatches_dev (must be 0). */
+/* Self-test (tests only): the fusion kernels divide uint16 pixels by float32 gains with a shortened
+ * sequence that is exact for gains with 2^-100 <= |g| < 2^100.  This compares its
+ * final clipped integers, truncated (overwrite mode) and rounded (feather mode), with the IEEE path for ALL 2^23 gain
+ * mantissas x all 65536 numerators in n_binades consecutive binades starting at 2^exponent (allowed:
+ * -100..99), either sign, and leaves the number of differing results in *mismatches_dev (must be 0). */
 int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
                             void *stream);
 

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image_stitcher_amd import native, placement, registration, synth
 dev = torch.device('cuda:0')
-g, T, OV, P = 16, 2048, 244, 2
+g, T, OV, P = 16, 2048, 244, 4
 spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=OV, ov_x=OV, seed=5)
 tiles = torch.empty((P, g * g, T, T), dtype=torch.uint16, device=dev)
 for p in range(P):
@@ -27,10 +27,14 @@ wc, hc = placement.canvas_size(g, g, T, T, use_registration=True, shifts=shifts)
 rects = placement.grid_rects(g, g, T, T, shifts, crop=False)
 plan = native.FusePlan(rects, T, T, hc, wc, native.SQ_FUSE_FEATHER)
 print(f'feather plan: {plan.n_spans} spans, {plan.n_items} items, max refs {plan.max_refs}')
-for dt in (torch.uint16, torch.float32):
+ff = torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32)).to(dev)
+rho = g * g * T * T / (hc * wc)
+for dt, flats in ((torch.uint16, None), (torch.uint16, [ff] * P), (torch.float32, None)):
     canvas = torch.empty((P, hc, wc), dtype=dt, device=dev)
-    t = timeit(lambda: native.fuse_planes(plan, tiles, canvas))
-    print(f'feather -> {dt}: {t*1e3:.2f} ms for {P} planes -> {P*hc*wc/t/1e6:.0f} Mvoxel/s')
+    t = timeit(lambda: native.fuse_planes(plan, tiles, canvas, flats))
+    alg = P * hc * wc * (2 * rho + canvas.element_size())       # 2*rho B read + the voxel written
+    print(f'feather -> {dt}{" with float32 gains" if flats else ""}: {t*1e3:.2f} ms for {P} planes -> '
+          f'{P*hc*wc/t/1e6:.0f} Mvoxel/s, {alg/t/1e9:.0f} GB/s algorithmic ({alg/t/8e12:.3f} of 8 TB/s)')
     del canvas
 xs = [spec.stage_mm(0, c)[0] for c in range(g)]
 ys = [spec.stage_mm(r, 0)[1] for r in range(g)]
