@@ -531,41 +531,75 @@ __device__ __forceinline__ int posmod(long long a, int m) {
 // ---------------------------------------------------------------------------------------------
 // K4b: D1[k0][b] = sum_{k1 < n1} P[k0][k1] * exp(+2 pi i (b - off1) f1[k1])
 // ---------------------------------------------------------------------------------------------
+// A small complex GEMM per pair: [n0 x n1] spectrum times the [n1 x R] phase matrix
+// W[k1][b] = E[((b - off1) * f1[k1]) mod M], which depends on the pair (through its peak) but not on
+// k0 -- so it is built once per block and reused by every row of the block's tile instead of being
+// looked up per element (the first version did that, with a 64-bit modulo each, and reduced across
+// the block once per output: 42 % of an all-pairs batch).
+// Block = 128 rows k0 of one pair, 256 threads, thread tile = 2 rows x 4 outputs, the k1 range in
+// chunks of 16 staged through LDS (row pitch padded by one element: the 16 rows a wave reads at one
+// k1 fall into distinct banks).  Every output is summed over k1 in ascending order by one thread:
+// no cross-thread reduction, nothing depends on scheduling.
+constexpr int UR_ROWS = 128, UR_KC = 16, UR_B = 16;
 __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, R = L.region, up = L.up;
-    const int pair = blockIdx.y, k0 = blockIdx.x;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int pair = blockIdx.y, row0 = blockIdx.x * UR_ROWS;
+    const int tid = threadIdx.x;
     const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
     // shifts = round(shifts*u)/u is the integer peak; offset = fix(R/2) - shift*u (skimage :232-238)
     const int off1 = R / 2 - pk[1] * up;
     const cplx *Pm = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)n0 * n1h;
-    const cplx *row = Pm + (int64_t)k0 * n1h;
-    const cplx *mir = Pm + (int64_t)((n0 - k0) % n0) * n1h;   // P[k0][n1-k] = conj P[-k0][k]
     const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up1);
     const int M = n1 * up;
-    __shared__ cplx part[4];
-    cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + k0) * R;
-    for (int b = 0; b < R; ++b) {
-        cplx acc = {0.0, 0.0};
-        const long long mb = b - off1;
-        for (int k1 = tid; k1 < n1; k1 += nt) {
-            const cplx v = k1 < n1h ? row[k1] : cconj(mir[n1 - k1]);
-            const cplx e = E[posmod(mb * signed_freq(k1, n1), M)];
-            acc = cadd(acc, cmul(v, e));
+    __shared__ cplx Pl[UR_ROWS][UR_KC + 1];
+    __shared__ cplx Wl[UR_KC][UR_B];
+    const int r2 = tid >> 2, bq = tid & 3;   // rows 2*r2, 2*r2+1; outputs 4*bq .. 4*bq+3 of the chunk
+    for (int b0 = 0; b0 < R; b0 += UR_B) {
+        cplx acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = {0.0, 0.0};
+        for (int kc = 0; kc < n1; kc += UR_KC) {
+            // stage the spectrum tile: P[k0][k1] for k1 < n1h, conj P[-k0][n1 - k1] beyond (Hermitian half)
+            for (int e = tid; e < UR_ROWS * UR_KC; e += 256) {
+                const int i = e / UR_KC, k = e - i * UR_KC;
+                const int k0 = row0 + i, k1 = kc + k;
+                cplx v = {0.0, 0.0};
+                if (k0 < n0 && k1 < n1)
+                    v = k1 < n1h ? Pm[(int64_t)k0 * n1h + k1] : cconj(Pm[(int64_t)((n0 - k0) % n0) * n1h + (n1 - k1)]);
+                Pl[i][k] = v;
+            }
+            {   // and the phase tile: one entry per thread
+                const int k = tid / UR_B, b = tid - k * UR_B;
+                const int k1 = kc + k;
+                cplx w = {0.0, 0.0};
+                if (k1 < n1 && b0 + b < R) w = E[posmod((long long)(b0 + b - off1) * signed_freq(k1, n1), M)];
+                Wl[k][b] = w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UR_KC; ++k) {
+                const cplx p0 = Pl[2 * r2][k], p1 = Pl[2 * r2 + 1][k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const cplx w = Wl[k][4 * bq + j];
+                    acc[0][j] = cadd(acc[0][j], cmul(p0, w));
+                    acc[1][j] = cadd(acc[1][j], cmul(p1, w));
+                }
+            }
+            __syncthreads();
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            acc.re += __shfl_xor(acc.re, o);
-            acc.im += __shfl_xor(acc.im, o);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k0 = row0 + 2 * r2 + i;
+            if (k0 >= n0) continue;
+            cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + k0) * R;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (b0 + 4 * bq + j < R) D1[b0 + 4 * bq + j] = acc[i][j];
         }
-        if ((tid & 63) == 0) part[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            cplx s = part[0];
-            for (int w = 1; w < (nt >> 6); ++w) s = cadd(s, part[w]);
-            D1[b] = s;
-        }
-        __syncthreads();
     }
 }
 
@@ -771,7 +805,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     hipLaunchKernelGGL(rows_inverse_kernel, dim3((L.n0 + 1) / 2, a->n_pairs), dim3(nt1), lds_row, s, P);
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
-        hipLaunchKernelGGL(upsample_rows_kernel, dim3(L.n0, a->n_pairs), dim3(pick_threads(L.n1)), 0, s, P);
+        hipLaunchKernelGGL(upsample_rows_kernel, dim3((L.n0 + UR_ROWS - 1) / UR_ROWS, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_cols_kernel, dim3(L.region, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     }
