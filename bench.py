@@ -136,6 +136,7 @@ def main():
 
     fuse_events = []
     state = {}
+    gathers = []
 
     lap = {}
 
@@ -152,8 +153,11 @@ def main():
         shifts = registration.register_grid_center(reg_plane, g, g, xs, ys, spec.pixel_size_um,
                                                    spec.pixel_binning, normalization='phase')
         t = tick('register', t)
-        table = sharding.all_gather_shift_table(sharding.shifts_to_row(shifts)[None], device=coll_dev)
-        mine = sharding.row_to_shifts(table[rank])
+        # the shift table is all-gathered (RCCL) beside the fusion launch: a rank fuses with its own
+        # region's shifts, the other rows are only needed when the table is written out
+        row = sharding.shifts_to_row(shifts)
+        gathers.append((row, sharding.all_gather_shift_table_async(row[None], device=coll_dev)))
+        mine = sharding.row_to_shifts(row)
         t = tick('allgather', t)
         # host integer geometry + span plan (rebuilt every step: it depends on the shifts)
         rects = placement.grid_rects(g, g, TILE, TILE, mine, order=order_rc)
@@ -173,7 +177,15 @@ def main():
         state['plan'], state['shifts'] = plan, mine
         tick('fuse_launch', t)
 
+    def finish_gathers():
+        # inside the timed region: every step's table has arrived and holds this rank's row
+        for row, pending in gathers:
+            table = pending.result()
+            assert table.shape == (world, sharding.SHIFT_ROW) and (table[rank] == row).all(), "shift table all-gather"
+        gathers.clear()
+
     def fence():
+        finish_gathers()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

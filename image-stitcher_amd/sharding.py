@@ -78,21 +78,43 @@ def row_to_shifts(row: Sequence[int]) -> Optional[Shifts]:
     return Shifts((row[1], row[2]), (row[3], row[4]), rev, row[7])
 
 
-def all_gather_shift_table(local_rows: np.ndarray, device=None, group=None) -> np.ndarray:
-    """Every rank contributes ``local_rows`` [k, SHIFT_ROW] int32 (same k on every rank) and gets the
-    table [world * k, SHIFT_ROW] back, rank-major.  Single process: returns the input."""
+class PendingShiftTable:
+    """An all-gather of shift rows in flight; ``result()`` waits for it and returns the table."""
+
+    def __init__(self, table=None, work=None, out=None, keep=None):
+        self._table, self._work, self._out, self._keep = table, work, out, keep
+
+    def result(self) -> np.ndarray:
+        if self._table is None:
+            self._work.wait()
+            self._table = self._out.cpu().numpy().reshape(-1, SHIFT_ROW)
+            self._work = self._out = self._keep = None
+        return self._table
+
+
+def all_gather_shift_table_async(local_rows: np.ndarray, device=None, group=None) -> PendingShiftTable:
+    """Start the all-gather of ``local_rows`` [k, SHIFT_ROW] int32 (same k on every rank) and return at
+    once.  Nothing on a rank's own data path needs the other ranks' rows (every rank fuses with the
+    shifts of its own regions), so the collective runs beside the fusion launch on RCCL's stream and
+    is only waited for when the table is written out."""
     import torch
     import torch.distributed as dist
     local_rows = np.ascontiguousarray(local_rows, dtype=np.int32).reshape(-1, SHIFT_ROW)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local_rows.copy()
+        return PendingShiftTable(table=local_rows.copy())
     world = dist.get_world_size(group)
     t = torch.from_numpy(local_rows)
     if device is not None:
         t = t.to(device)
     out = torch.empty((world * t.shape[0], SHIFT_ROW), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t, group=group)
-    return out.cpu().numpy().reshape(-1, SHIFT_ROW)
+    work = dist.all_gather_into_tensor(out, t, group=group, async_op=True)
+    return PendingShiftTable(work=work, out=out, keep=t)
+
+
+def all_gather_shift_table(local_rows: np.ndarray, device=None, group=None) -> np.ndarray:
+    """Every rank contributes ``local_rows`` [k, SHIFT_ROW] int32 (same k on every rank) and gets the
+    table [world * k, SHIFT_ROW] back, rank-major.  Single process: returns the input."""
+    return all_gather_shift_table_async(local_rows, device, group).result()
 
 
 def first_valid(table: np.ndarray) -> Optional[Shifts]:

@@ -38,6 +38,7 @@ def test_shift_rows_roundtrip():
     # single process: the gather is the identity
     rows = sharding.shifts_to_row(Shifts((1, 2), (3, 4)))[None]
     np.testing.assert_array_equal(sharding.all_gather_shift_table(rows), rows)
+    np.testing.assert_array_equal(sharding.all_gather_shift_table_async(rows).result(), rows)
 
 
 def _free_port():
@@ -67,6 +68,13 @@ def _worker(rank, world, port, out_dir):
             want = S((r, -100 - r), (-200 - r, r), (7, 8) if r == 0 else None, r if r == 0 else 0)
             got = sh.row_to_shifts(table[r])
             assert got.h_shift == want.h_shift and got.v_shift == want.v_shift and got.h_shift_rev == want.h_shift_rev
+        # several gathers in flight (the bench overlaps them with the fusion launches), collected later
+        rows = [np.full((1, sh.SHIFT_ROW), 10 * k + rank, dtype=np.int32) for k in range(3)]
+        pending = [sh.all_gather_shift_table_async(r) for r in rows]
+        for k, pnd in enumerate(pending):
+            got = pnd.result()
+            assert got.shape == (world, sh.SHIFT_ROW) and [int(v) for v in got[:, 0]] == [10 * k + r for r in range(world)]
+            assert pnd.result() is got          # idempotent
         # planes dealt block-cyclically: the union over ranks is every plane exactly once
         planes = torch.zeros(40, dtype=torch.int32)
         planes[sh.block_cyclic(40, rank, world)] = 1
