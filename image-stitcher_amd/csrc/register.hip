@@ -113,62 +113,94 @@ __device__ __forceinline__ bool pair_ok(const RegParams &P, const sq_pair &pr) {
 // ---------------------------------------------------------------------------------------------
 // line FFT in LDS
 // ---------------------------------------------------------------------------------------------
-// Power of two: in-place radix-2 decimation in time; tw[k] = exp(-2 pi i k / n), k < n/2.
-// Otherwise: direct DFT with tw[j] = exp(-2 pi i j / n), j < n, result written back to x via tmp.
+// Power of two: in-place radix-2 decimation in time, tw[k] = exp(-2 pi i k / n), k < n/2, with two
+// stages fused per pass: the four points {i, i+h, i+2h, i+3h} are closed under stages s and s+1, so a
+// thread carries them through both in registers -- the arithmetic (and so every bit of the result)
+// is that of the plain radix-2 schedule, with half the LDS passes and barriers.  All `nlines` lines
+// of the block (contiguous, n points each) go through every pass together: one barrier per pass for
+// the whole batch instead of one per line.
+// Otherwise: direct DFT with tw[j] = exp(-2 pi i j / n), j < n, line by line, result written back via tmp.
 // INV conjugates the twiddles (no 1/n scaling anywhere: only argmax and ratios are used).
 template <bool INV>
-__device__ void line_fft(cplx *x, cplx *tmp, int n, const cplx *__restrict__ tw, int tid, int nt) {
+__device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
+    cplx w = tw[idx];
+    if (INV) w.im = -w.im;
+    return w;
+}
+
+template <bool INV>
+__device__ void lines_fft(cplx *base, cplx *tmp, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
     if ((n & (n - 1)) == 0) {
         const int logn = 31 - __clz(n);
-        for (int i = tid; i < n; i += nt) {
-            const int j = (int)(__brev((unsigned)i) >> (32 - logn));
+        for (int e = tid; e < nlines * n; e += nt) {
+            const int i = e & (n - 1);
+            const int j = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
             if (i < j) {
+                cplx *x = base + (e - i);
                 const cplx a = x[i];
                 x[i] = x[j];
                 x[j] = a;
             }
         }
         __syncthreads();
-        for (int s = 1; s <= logn; ++s) {
+        int s = 1;
+        if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
+            for (int e = tid; e < nlines * (n >> 1); e += nt) {
+                cplx *x = base + 2 * (int64_t)e;
+                const cplx t = cmul(twiddle<INV>(tw, 0), x[1]);
+                const cplx u = x[0];
+                x[0] = cadd(u, t);
+                x[1] = csub(u, t);
+            }
+            __syncthreads();
+            s = 2;
+        }
+        const int quads = n >> 2;
+        for (; s < logn; s += 2) {
             const int half = 1 << (s - 1);
-            const int tstride = n >> s;
-            for (int b = tid; b < n / 2; b += nt) {
-                const int k = b & (half - 1);
-                const int i = ((b >> (s - 1)) << s) + k;
-                cplx w = tw[k * tstride];
-                if (INV) w.im = -w.im;
-                const cplx t = cmul(w, x[i + half]);
-                const cplx u = x[i];
-                x[i] = cadd(u, t);
-                x[i + half] = csub(u, t);
+            const int ts1 = n >> s, ts2 = n >> (s + 1);
+            for (int e = tid; e < nlines * quads; e += nt) {
+                const int l = e / quads, q = e - l * quads;
+                const int k = q & (half - 1);
+                cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
+                const cplx w1 = twiddle<INV>(tw, k * ts1);
+                const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
+                const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
+                // stage s: (x0, x1) and (x2, x3), both with w1
+                const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
+                const cplx a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
+                // stage s + 1: (a0, a2) with w2, (a1, a3) with w3
+                const cplx u2 = cmul(w2, a2), u3 = cmul(w3, a3);
+                x[0] = cadd(a0, u2);
+                x[2 * half] = csub(a0, u2);
+                x[half] = cadd(a1, u3);
+                x[3 * half] = csub(a1, u3);
             }
             __syncthreads();
         }
     } else {
-        for (int k = tid; k < n; k += nt) {
-            cplx acc = {0.0, 0.0};
-            int idx = 0;
-            for (int j = 0; j < n; ++j) {
-                cplx w = tw[idx];
-                if (INV) w.im = -w.im;
-                acc = cadd(acc, cmul(x[j], w));
-                idx += k;
-                if (idx >= n) idx -= n;
+        for (int l = 0; l < nlines; ++l) {
+            cplx *x = base + (int64_t)l * n;
+            for (int k = tid; k < n; k += nt) {
+                cplx acc = {0.0, 0.0};
+                int idx = 0;
+                for (int j = 0; j < n; ++j) {
+                    acc = cadd(acc, cmul(x[j], twiddle<INV>(tw, idx)));
+                    idx += k;
+                    if (idx >= n) idx -= n;
+                }
+                tmp[k] = acc;
             }
-            tmp[k] = acc;
+            __syncthreads();
+            for (int k = tid; k < n; k += nt) x[k] = tmp[k];
+            __syncthreads();
         }
-        __syncthreads();
-        for (int k = tid; k < n; k += nt) x[k] = tmp[k];
-        __syncthreads();
     }
 }
 
-// several independent lines in one block: the block's threads are split into groups of `tpl`
-// threads, one group per line; all groups execute the same barriers.
 template <bool INV>
-__device__ void lines_fft(cplx *base, cplx *tmpbase, int n, int nlines, const cplx *tw, int tid, int nt) {
-    // every thread walks all lines (barriers must be uniform); threads stride inside a line
-    for (int l = 0; l < nlines; ++l) line_fft<INV>(base + (int64_t)l * n, tmpbase, n, tw, tid, nt);
+__device__ __forceinline__ void line_fft(cplx *x, cplx *tmp, int n, const cplx *__restrict__ tw, int tid, int nt) {
+    lines_fft<INV>(x, tmp, n, 1, tw, tid, nt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -325,14 +357,17 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
 // ---------------------------------------------------------------------------------------------
 // K2: columns -- FFT both spectra along axis 0, cross-power product, inverse along axis 0
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void columns_kernel(RegParams P) {
+#ifndef SQ_COL_THREADS
+#define SQ_COL_THREADS 512
+#endif
+__global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n0 = L.n0, n1h = L.n1h, tc = P.tc;
     cplx *f = reinterpret_cast<cplx *>(smem);   // [tc][n0]
     cplx *g = f + (int64_t)tc * n0;             // [tc][n0]
     cplx *tmp = g + (int64_t)tc * n0;           // [n0] (direct DFT only)
-    __shared__ double red[2][4];
+    __shared__ double red[2][SQ_COL_THREADS / 64];
     const int pair = blockIdx.y, c0 = blockIdx.x * tc;
     const int ncol = min(tc, n1h - c0);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -345,8 +380,12 @@ __global__ __launch_bounds__(256) void columns_kernel(RegParams P) {
     }
     __syncthreads();
     const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
-    lines_fft<false>(f, tmp, n0, ncol, tw0, tid, nt);
-    lines_fft<false>(g, tmp, n0, ncol, tw0, tid, nt);
+    if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
+        lines_fft<false>(f, tmp, n0, 2 * tc, tw0, tid, nt);
+    } else {
+        lines_fft<false>(f, tmp, n0, ncol, tw0, tid, nt);
+        lines_fft<false>(g, tmp, n0, ncol, tw0, tid, nt);
+    }
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
     for (int c = 0; c < ncol; ++c) {
@@ -801,7 +840,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
         if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(256), lds_col, s, P);
+    hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
     hipLaunchKernelGGL(rows_inverse_kernel, dim3((L.n0 + 1) / 2, a->n_pairs), dim3(nt1), lds_row, s, P);
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
