@@ -575,15 +575,19 @@ __device__ __forceinline__ int posmod(long long a, int m) {
 // k0 -- so it is built once per block and reused by every row of the block's tile instead of being
 // looked up per element (the first version did that, with a 64-bit modulo each, and reduced across
 // the block once per output: 42 % of an all-pairs batch).
-// Block = 128 rows k0 of one pair, 256 threads, thread tile = 2 rows x 4 outputs, the k1 range in
-// chunks of 16 staged through LDS (row pitch padded by one element: the 16 rows a wave reads at one
+// Block = 128 (or 16) rows k0 of one pair, 256 threads, thread tile = 2 rows x 4 outputs (or 1 x 1), the k1 range in
+// chunks of 16 (64 in the small variant) staged through LDS (row pitch padded by one element: the 16 rows a wave reads at one
 // k1 fall into distinct banks).  Every output is summed over k1 in ascending order by one thread:
 // no cross-thread reduction, nothing depends on scheduling.
-constexpr int UR_ROWS = 128, UR_KC = 16, UR_B = 16;
+// Thread tile TR rows x TB outputs: 2 x 4 (128 rows per block) for batches, 1 x 1 (16 rows per block)
+// when there are too few pairs to fill the chip with 128-row blocks (the bench's two centre pairs).
+constexpr int UR_B = 16;
+template <int TR, int TB, int UR_KC>
 __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
+    constexpr int ROWS = 256 / (UR_B / TB) * TR;
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, R = L.region, up = L.up;
-    const int pair = blockIdx.y, row0 = blockIdx.x * UR_ROWS;
+    const int pair = blockIdx.y, row0 = blockIdx.x * ROWS;
     const int tid = threadIdx.x;
     const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
     // shifts = round(shifts*u)/u is the integer peak; offset = fix(R/2) - shift*u (skimage :232-238)
@@ -591,18 +595,18 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
     const cplx *Pm = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)n0 * n1h;
     const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up1);
     const int M = n1 * up;
-    __shared__ cplx Pl[UR_ROWS][UR_KC + 1];
+    __shared__ cplx Pl[ROWS][UR_KC + 1];
     __shared__ cplx Wl[UR_KC][UR_B];
-    const int r2 = tid >> 2, bq = tid & 3;   // rows 2*r2, 2*r2+1; outputs 4*bq .. 4*bq+3 of the chunk
+    const int rt = tid / (UR_B / TB), bt = tid % (UR_B / TB);   // rows TR*rt .., outputs TB*bt .. of the chunk
     for (int b0 = 0; b0 < R; b0 += UR_B) {
-        cplx acc[2][4];
+        cplx acc[TR][TB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TR; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = {0.0, 0.0};
+            for (int j = 0; j < TB; ++j) acc[i][j] = {0.0, 0.0};
         for (int kc = 0; kc < n1; kc += UR_KC) {
             // stage the spectrum tile: P[k0][k1] for k1 < n1h, conj P[-k0][n1 - k1] beyond (Hermitian half)
-            for (int e = tid; e < UR_ROWS * UR_KC; e += 256) {
+            for (int e = tid; e < ROWS * UR_KC; e += 256) {
                 const int i = e / UR_KC, k = e - i * UR_KC;
                 const int k0 = row0 + i, k1 = kc + k;
                 cplx v = {0.0, 0.0};
@@ -610,8 +614,8 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
                     v = k1 < n1h ? Pm[(int64_t)k0 * n1h + k1] : cconj(Pm[(int64_t)((n0 - k0) % n0) * n1h + (n1 - k1)]);
                 Pl[i][k] = v;
             }
-            {   // and the phase tile: one entry per thread
-                const int k = tid / UR_B, b = tid - k * UR_B;
+            for (int e = tid; e < UR_KC * UR_B; e += 256) {   // and the phase tile
+                const int k = e / UR_B, b = e - k * UR_B;
                 const int k1 = kc + k;
                 cplx w = {0.0, 0.0};
                 if (k1 < n1 && b0 + b < R) w = E[posmod((long long)(b0 + b - off1) * signed_freq(k1, n1), M)];
@@ -620,24 +624,26 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < UR_KC; ++k) {
-                const cplx p0 = Pl[2 * r2][k], p1 = Pl[2 * r2 + 1][k];
+                cplx p[TR];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const cplx w = Wl[k][4 * bq + j];
-                    acc[0][j] = cadd(acc[0][j], cmul(p0, w));
-                    acc[1][j] = cadd(acc[1][j], cmul(p1, w));
+                for (int i = 0; i < TR; ++i) p[i] = Pl[TR * rt + i][k];
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    const cplx w = Wl[k][TB * bt + j];
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) acc[i][j] = cadd(acc[i][j], cmul(p[i], w));
                 }
             }
             __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k0 = row0 + 2 * r2 + i;
+        for (int i = 0; i < TR; ++i) {
+            const int k0 = row0 + TR * rt + i;
             if (k0 >= n0) continue;
             cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + k0) * R;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (b0 + 4 * bq + j < R) D1[b0 + 4 * bq + j] = acc[i][j];
+            for (int j = 0; j < TB; ++j)
+                if (b0 + TB * bt + j < R) D1[b0 + TB * bt + j] = acc[i][j];
         }
     }
 }
@@ -844,7 +850,10 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     hipLaunchKernelGGL(rows_inverse_kernel, dim3((L.n0 + 1) / 2, a->n_pairs), dim3(nt1), lds_row, s, P);
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
-        hipLaunchKernelGGL(upsample_rows_kernel, dim3((L.n0 + UR_ROWS - 1) / UR_ROWS, a->n_pairs), dim3(256), 0, s, P);
+        if ((int64_t)a->n_pairs * ((L.n0 + 127) / 128) >= 256)
+            hipLaunchKernelGGL((upsample_rows_kernel<2, 4, 16>), dim3((L.n0 + 127) / 128, a->n_pairs), dim3(256), 0, s, P);
+        else
+            hipLaunchKernelGGL((upsample_rows_kernel<1, 1, 64>), dim3((L.n0 + 15) / 16, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_cols_kernel, dim3(L.region, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     }
