@@ -523,9 +523,15 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
     const int pair = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int nrp = (L.n0 + 1) / 2;
     const double *rm = reinterpret_cast<const double *>(P.ws + L.rowmax) + (int64_t)pair * nrp * 2;
+    // the column energies are summed by one thread in column order (a fixed order: the sums are
+    // outputs); staging them through LDS first turns its chain of dependent global loads into one
+    // coalesced read by the block
+    __shared__ double amp_l[2 * (MAX_POW2 / 2 + 1)];
+    const double *amps = reinterpret_cast<const double *>(P.ws + L.amps) + (int64_t)pair * L.n1h * 2;
+    for (int i = tid; i < 2 * L.n1h; i += nt) amp_l[i] = amps[i];
     Best best = {-1.0, (long long)1 << 62, 0};
     for (int i = tid; i < nrp; i += nt) best = better(best, make_best(rm[2 * i], reinterpret_cast<const long long *>(rm)[2 * i + 1]));
-    best = block_best(best, tid, nt);
+    best = block_best(best, tid, nt);   // contains the barriers that publish amp_l
     if (tid == 0) {
         const int py = (int)(best.idx / L.n1), px = (int)(best.idx % L.n1);
         // shifts[shifts > fix(n/2)] -= n   (skimage :217-220)
@@ -543,13 +549,12 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
         // the upsampled stage overwrites this with the complex value when u > 1
         res.ccmax_re = best.v / ((double)L.n0 * (double)L.n1);
         res.ccmax_im = 0.0;
-        const double *amps = reinterpret_cast<const double *>(P.ws + L.amps) + (int64_t)pair * L.n1h * 2;
         double sa = 0.0, sb = 0.0;
         for (int k = 0; k < L.n1h; ++k) {
             // a column and its Hermitian mirror carry the same energy
             const double wgt = (k == 0 || (2 * k == L.n1)) ? 1.0 : 2.0;
-            sa += wgt * amps[2 * k];
-            sb += wgt * amps[2 * k + 1];
+            sa += wgt * amp_l[2 * k];
+            sb += wgt * amp_l[2 * k + 1];
         }
         if (L.up == 1) {   // skimage :224-228 divides by size in this branch only
             sa /= (double)L.n0 * (double)L.n1;
@@ -670,9 +675,18 @@ __global__ __launch_bounds__(256) void upsample_cols_kernel(RegParams P) {
         cplx acc = {0.0, 0.0};
         if (b < R) {
             const int k_lo = (int)((int64_t)n0 * slice / 16), k_hi = (int)((int64_t)n0 * (slice + 1) / 16);
+            // the phase index advances by (a - off0) mod M from one k0 to the next, except where the
+            // signed frequency wraps from positive to negative
+            const int step = posmod(ma, M), wrap = (n0 - 1) / 2 + 1;
+            int idx = 0;
             for (int k0 = k_lo; k0 < k_hi; ++k0) {
-                const cplx e = E[posmod(ma * signed_freq(k0, n0), M)];
-                acc = cadd(acc, cmul(D1[(int64_t)k0 * R + b], e));
+                if (k0 == k_lo || k0 == wrap) {
+                    idx = posmod(ma * signed_freq(k0, n0), M);
+                } else {
+                    idx += step;
+                    if (idx >= M) idx -= M;
+                }
+                acc = cadd(acc, cmul(D1[(int64_t)k0 * R + b], E[idx]));
             }
         }
         part[slice][tid & 15] = acc;
