@@ -141,15 +141,17 @@ __device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
 // mantissas per binade that fail, e.g. 4075 / 0x1.dbf3fep-3).  This is the full IEEE sequence
 // (Newton step on the reciprocal, quotient, two exact-residual corrections) minus its v_div_scale /
 // v_div_fmas / v_div_fixup range handling, which this operand class never needs: 8 slots, not 11.
-template <int RND>
-__device__ __forceinline__ float quotient_u16_normal(float n, float g) {
-    if (!RND) return div_u16_normal(n, g);
+__device__ __forceinline__ float div_u16_normal_ieee(float n, float g) {
     float r = __builtin_amdgcn_rcpf(g);
     r = fmaf(fmaf(-g, r, 1.0f), r, r);
     float q = n * r;
     q = fmaf(fmaf(-g, q, n), r, q);
-    q = fmaf(fmaf(-g, q, n), r, q);
-    return __builtin_rintf(q);   // v_rndne_f32
+    return fmaf(fmaf(-g, q, n), r, q);
+}
+template <int RND>
+__device__ __forceinline__ float quotient_u16_normal(float n, float g) {
+    if (!RND) return div_u16_normal(n, g);
+    return __builtin_rintf(div_u16_normal_ieee(n, g));   // v_rndne_f32
 }
 template <typename T, int RND = 0>
 __device__ __forceinline__ T flat_f32_fast(T v, float g) {
@@ -487,7 +489,7 @@ __device__ __forceinline__ OutT feather_out(float o) {
 // One 8-pixel group (p0 .. p0+7 of item row r) blended from the item's references.  The loads of up
 // to four references (pixels and gains) are issued before the first use; references are
 // wave-uniform, so the loops over them run on scalar registers.
-template <typename T, typename OutT, int FLAT>
+template <typename T, typename OutT, int FLAT, bool FAST>
 __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, const Item &it, const char *flat, int r, int p0,
                                             OutT *dst) {
     constexpr int VEC = 8;
@@ -531,7 +533,7 @@ __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, cons
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     px[e] = (float)Pix<uint16_t>::get(raw[k], e);
-                    if (FLAT == 1 && flat) px[e] = __fdiv_rn(px[e], g[k][e >> 2][e & 3]);
+                    if (FLAT == 1 && flat) px[e] = FAST ? div_u16_normal_ieee(px[e], g[k][e >> 2][e & 3]) : __fdiv_rn(px[e], g[k][e >> 2][e & 3]);
                 }
                 blend(px, ys[k], xs[k]);
             }
@@ -556,7 +558,7 @@ __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, cons
                 for (int e = 0; e < VEC; ++e) {
                     const char *gp = flat + ((int64_t)y * P.tile_w + x0 + e) * (FLAT == 2 ? 8 : 4);
                     const float gain = FLAT == 2 ? (float)ldg_s<double>(gp) : ldg_s<float>(gp);
-                    px[e] = __fdiv_rn(px[e], gain);
+                    px[e] = FAST ? div_u16_normal_ieee(px[e], gain) : __fdiv_rn(px[e], gain);
                 }
             }
             blend(px, y, x0);
@@ -588,7 +590,7 @@ __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, cons
 // A blended item: its (row, 8-pixel group) pairs are dealt to the 256 threads of the workgroup, so a
 // narrow overlap strip (244 pixels = 30 groups per row) keeps every lane busy; stores are aligned to
 // the 8-pixel group of the canvas row, the pixels before / after the aligned body go one per thread.
-template <typename T, typename OutT, int FLAT>
+template <typename T, typename OutT, int FLAT, bool FAST>
 __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const Item &it, int tid) {
     constexpr int VEC = 8;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
@@ -603,7 +605,7 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
         const int v = (mis ? 1 : 0) + j;
         if (v >= (n + mis) / VEC) continue;
         const int p0 = v * VEC - mis;
-        blend_group<T, OutT, FLAT>(P, plane, it, flat, r, p0, drow + p0);
+        blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, drow + p0);
     }
     for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
         const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
@@ -627,7 +629,7 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
             if (FLAT && flat) {
                 const char *gp = flat + ((int64_t)y * P.tile_w + x) * (FLAT == 2 ? 8 : 4);
                 const float gain = FLAT == 2 ? (float)ldg_s<double>(gp) : ldg_s<float>(gp);
-                v = __fdiv_rn(v, gain);
+                v = FAST ? div_u16_normal_ieee(v, gain) : __fdiv_rn(v, gain);
             }
             const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
             acc = __fadd_rn(acc, __fmul_rn(w, v));
@@ -667,7 +669,11 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
             process_item<T, FLAT == 2 ? 0 : FLAT, 1>(P, plane, one, tile, wave, lane);
             continue;
         }
-        blend_item<T, OutT, FLAT>(P, plane, it, threadIdx.x);
+        // float32 gains the pre-pass found all normal: the 8-slot divide, bit-identical to the IEEE
+        // quotient for this operand class (exhaustive self-test), instead of the 11-slot generic one
+        const bool fast = FLAT == 1 && P.flat_class && P.flat_class[plane] == 0;
+        if (fast) blend_item<T, OutT, FLAT, true>(P, plane, it, threadIdx.x);
+        else blend_item<T, OutT, FLAT, false>(P, plane, it, threadIdx.x);
     }
 }
 
@@ -728,8 +734,11 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(int exponent0, int
         // rounded instead of truncated (feather mode, voxels one tile covers).  NB the quotient float
         // itself is NOT always the IEEE one: n/g can sit within 2^-48 of a float midpoint, closer than the
         // sequence's 2^-46 error, while integer and half-integer boundaries are >= 2^-41 away -- so only
-        // results that end in an integer may use it; the blend of several tiles divides the IEEE way.
+        // truncated results may use it; rounded and blended ones take div_u16_normal_ieee.
         local += flat_f32<uint16_t, 1>((uint16_t)v, g) != flat_f32_fast<uint16_t, 1>((uint16_t)v, g);
+        // and the 8-slot sequence yields the IEEE quotient itself, bit for bit (the blend of several
+        // tiles uses the quotient as a float)
+        local += __fdiv_rn((float)v, g) != div_u16_normal_ieee((float)v, g);
 #ifdef SQ_SELFTEST_DEBUG
         if (flat_f32<uint16_t, 1>((uint16_t)v, g) != flat_f32_fast<uint16_t, 1>((uint16_t)v, g) && atomicAdd(bad + 1, 1ull) < 8)
             printf("rint mismatch v=%d g=%a (%08x): ieee q=%a -> %u, fast q=%a -> %u\n", v, g, bits, __fdiv_rn((float)v, g),
