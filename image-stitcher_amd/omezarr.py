@@ -216,9 +216,10 @@ class PlaneStreamWriter:
     Two slots, each = a device canvas of ``batch`` planes, device buffers for its pyramid levels and
     pinned host mirrors of all of them.  ``acquire(m)`` hands out the slot's canvas (waiting until the
     slot's previous contents are on disk); the caller fuses into it on the current stream and calls
-    ``submit(coords)``, which enqueues the pyramid kernels and the D2H copies behind the fusion and
-    returns at once; a dispatcher thread waits for the copies and fans the chunks out to the
-    compression threads.  So batch k is compressed and written while batch k+1 is read, copied and fused.
+    ``submit(coords)``, which enqueues the pyramid kernels behind the fusion and the D2H copies on a
+    separate copy stream behind those, and returns at once; a dispatcher thread waits for the copies
+    and fans the chunks out to the compression threads.  So batch k is copied out, compressed and
+    written while batch k+1 is read, copied in and fused.
     """
 
     def __init__(self, path: str, shapes: Sequence[tuple], dtype, *, chunks=(1, 1, 1, 512, 512), batch: int = 1,
@@ -235,6 +236,9 @@ class PlaneStreamWriter:
         yx = [tuple(s[3:]) for s in shapes]
         self._dev = [[torch.empty((self.batch,) + s, dtype=tdtype, device=device) for s in yx] for _ in range(slots)]
         self._host = [[torch.empty((self.batch,) + s, dtype=tdtype, pin_memory=True) for s in yx] for _ in range(slots)]
+        # D2H copies run on their own stream: the link is full duplex, so batch k leaves the device while
+        # batch k+1's tiles arrive and are fused on the caller's stream
+        self._copy_stream = torch.cuda.Stream(device=device)
         self._free = [threading.Event() for _ in range(slots)]
         for e in self._free:
             e.set()
@@ -285,10 +289,14 @@ class PlaneStreamWriter:
             raise ValueError(f"{m} planes acquired, {len(coords)} coordinates given")
         dev = self._dev[slot]
         device_levels(dev[0][:m], len(dev), out=dev[1:])
-        for d, h in zip(dev, self._host[slot]):
-            h[:m].copy_(d[:m], non_blocking=True)
+        fused = torch.cuda.Event()
+        fused.record()                                  # fusion + pyramid of this slot, on the caller's stream
         event = torch.cuda.Event()
-        event.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(fused)
+            for d, h in zip(dev, self._host[slot]):
+                h[:m].copy_(d[:m], non_blocking=True)
+            event.record()
         self._free[slot].clear()
         self._queue.put((slot, list(coords), event))
 
