@@ -223,7 +223,8 @@ class PlaneStreamWriter:
     """
 
     def __init__(self, path: str, shapes: Sequence[tuple], dtype, *, chunks=(1, 1, 1, 512, 512), batch: int = 1,
-                 compression: str = 'zlib', level: int = 1, device='cuda:0', workers: Optional[int] = None, slots: int = 2):
+                 compression: str = 'zlib', level: int = 1, device='cuda:0', workers: Optional[int] = None, slots: int = 2,
+                 buffers=None):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -234,8 +235,17 @@ class PlaneStreamWriter:
         self.bytes_written = 0
         tdtype = native.torch_dtype_of(np.dtype(dtype).type)
         yx = [tuple(s[3:]) for s in shapes]
-        self._dev = [[torch.empty((self.batch,) + s, dtype=tdtype, device=device) for s in yx] for _ in range(slots)]
-        self._host = [[torch.empty((self.batch,) + s, dtype=tdtype, pin_memory=True) for s in yx] for _ in range(slots)]
+        # ``buffers``: the (device, pinned host) slot buffers of an earlier writer of the same geometry --
+        # page-locking host memory costs more than a small region's whole fusion, so callers that write
+        # many regions (one per well and timepoint) hand them on
+        if buffers is None:
+            buffers = ([[torch.empty((self.batch,) + s, dtype=tdtype, device=device) for s in yx] for _ in range(slots)],
+                       [[torch.empty((self.batch,) + s, dtype=tdtype, pin_memory=True) for s in yx] for _ in range(slots)])
+        self.buffers = buffers
+        self._dev, self._host = buffers
+        if len(self._dev) != slots or [tuple(t.shape) for t in self._dev[0]] != [(self.batch,) + s for s in yx] \
+                or self._dev[0][0].dtype != tdtype:
+            raise ValueError("buffers do not match this writer's geometry")
         # D2H copies run on their own stream: the link is full duplex, so batch k leaves the device while
         # batch k+1's tiles arrive and are fused on the caller's stream
         self._copy_stream = torch.cuda.Stream(device=device)

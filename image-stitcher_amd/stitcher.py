@@ -87,6 +87,7 @@ class Stitcher:
         self.batch_bytes_limit = 4 << 30          # tile bytes staged (pinned + device) per ingest batch
         self._device = device
         self._plan_cache: Dict[tuple, native.FusePlan] = {}
+        self._buffer_cache: Dict[tuple, object] = {}
         self.init_stitching_parameters()
 
     # ------------------------------------------------------------------ state
@@ -478,6 +479,13 @@ class Stitcher:
                 progress_callback(channel_index + 1, self.num_c)
 
     # ----------------------------------------------------------------- fusion
+    def _keep_buffers(self, key, bufs) -> None:
+        """Remember staging / slot buffers for the next region of the same geometry (page-locking host
+        memory is slow); one entry per kind, so a change of geometry releases the old ones."""
+        for k in [k for k in self._buffer_cache if k[0] == key[0] and k != key]:
+            del self._buffer_cache[k]
+        self._buffer_cache[key] = bufs
+
     def _plan_for(self, rects, tile_h, tile_w, canvas_h, canvas_w, mode) -> native.FusePlan:
         rects = np.asarray(rects, dtype=np.int64).reshape(-1, 6)
         key = (rects.tobytes(), tile_h, tile_w, canvas_h, canvas_w, mode)
@@ -605,8 +613,13 @@ class Stitcher:
                     batch = min(batch, writer.batch)
                 chunks = [plist[b0:b0 + batch] for b0 in range(0, len(plist), batch)]
                 n_slots = min(2, len(chunks))
-                staging = [torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)]
-                on_dev = [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)]
+                key = ('ingest', batch, n, th, tw, n_slots, np.dtype(self.dtype).str)
+                bufs = self._buffer_cache.get(key)
+                if bufs is None:   # pinned staging + device mirrors, kept for the next region of the same shape
+                    bufs = ([torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)],
+                            [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)])
+                    self._keep_buffers(key, bufs)
+                staging, on_dev = bufs
                 done = [None] * n_slots
                 for k, chunk in enumerate(chunks):
                     slot = k % n_slots
@@ -699,8 +712,11 @@ class Stitcher:
         made = []
 
         def make_writer(batch):
+            key = ('writer', tuple(tuple(s[3:]) for s in shapes), batch, np.dtype(self.dtype).str)
             made.append(omezarr.PlaneStreamWriter(output_path, shapes, self.dtype, chunks=self.chunks or (1, 1, 1, 512, 512),
-                                                  batch=batch, compression=self.zarr_compression, device=self.device))
+                                                  batch=batch, compression=self.zarr_compression, device=self.device,
+                                                  buffers=self._buffer_cache.get(key)))
+            self._keep_buffers(key, made[-1].buffers)
             return made[-1]
 
         _, ids = self.stitch_planes(timepoint, region, only_planes, progress_callback, stream_to=make_writer)
