@@ -54,7 +54,8 @@ class Signal:
 
 class Stitcher:
     def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
-                 normalization: Optional[str] = 'phase', zarr_compression: str = 'zlib'):
+                 normalization: Optional[str] = 'phase', zarr_compression: str = 'zlib',
+                 per_region_registration: bool = False):
         self.update_progress = Signal(int, int)
         self.getting_flatfields = Signal()
         self.starting_stitching = Signal()
@@ -84,6 +85,10 @@ class Stitcher:
         if zarr_compression not in ('zlib', 'none'):
             raise ValueError("zarr_compression must be 'zlib' or 'none'")
         self.zarr_compression = zarr_compression
+        # False: shifts are measured once, on the first timepoint and region, and used everywhere (the
+        # reference, stitcher.py:1244-1246).  True: every (timepoint, region) is registered on its own
+        # tiles before it is fused (BASELINE config 5: per-well registration).
+        self.per_region_registration = bool(per_region_registration) and self.use_registration
         self.batch_bytes_limit = 4 << 30          # tile bytes staged (pinned + device) per ingest batch
         self._device = device
         self._plan_cache: Dict[tuple, native.FusePlan] = {}
@@ -754,6 +759,44 @@ class Stitcher:
                        name=f"{region}_t{timepoint}")
         return output_path
 
+    def _write_shift_table(self, n_units, my_rows, rank, world, coll) -> None:
+        """``shift_table.json`` in the output folder: the shifts every (timepoint, region) was fused with.
+        With per-region registration every rank contributes the rows it measured: one all-gather of
+        ceil(units / world) rows of 8 int32 per rank (RCCL over xGMI with the nccl backend) -- the only
+        collective on the path."""
+        units = [(int(t), region) for t in self.timepoints for region in self.regions]
+        if self.per_region_registration:
+            per_rank = -(-n_units // world)
+            local = np.zeros((per_rank, sharding.SHIFT_ROW), dtype=np.int32)
+            index = np.full(per_rank, -1, dtype=np.int64)
+            for slot, (i, row) in enumerate(sorted(my_rows.items())):
+                local[slot], index[slot] = row, i
+            # the unit index travels in the row's spare high bits of column 0: valid flags use bits 0-1
+            local[:, 0] |= ((index + 1).astype(np.int32) << 8)
+            table = sharding.all_gather_shift_table(local, device=coll)
+            rows = {}
+            for row in table:
+                i = (int(row[0]) >> 8) - 1
+                if i >= 0:
+                    clean = row.copy()
+                    clean[0] &= 0xFF
+                    rows[i] = sharding.row_to_shifts(clean)
+        else:
+            rows = {i: self._shifts() for i in range(n_units)}
+        if rank != 0:
+            return
+        entries = []
+        for i, (t, region) in enumerate(units):
+            s = rows.get(i)
+            if s is None:
+                continue
+            e = {'timepoint': t, 'region': region, 'h_shift': [int(v) for v in s.h_shift], 'v_shift': [int(v) for v in s.v_shift]}
+            if s.h_shift_rev is not None:
+                e.update(h_shift_rev=[int(v) for v in s.h_shift_rev], h_shift_rev_odd=int(s.h_shift_rev_odd))
+            entries.append(e)
+        with open(os.path.join(self.output_folder, 'shift_table.json'), 'w') as fh:
+            json.dump({'per_region_registration': self.per_region_registration, 'shifts': entries}, fh, indent=1)
+
     # --------------------------------------------------------------------- run
     # The reference's Stitcher is a QThread: GUIs call start() and listen to the signals.  The same
     # three calls work here on a plain thread.
@@ -794,20 +837,30 @@ class Stitcher:
                 self.get_flatfields(progress_callback=self.update_progress.emit)
                 print("Time to calculate flatfields:", time.time() - stime)
             self.flatfields = sharding.broadcast_object(self.flatfields)   # the estimate samples tiles at random
-        if self.use_registration:
+        coll = sharding.collective_device(self)
+        if self.use_registration and not self.per_region_registration:
             if rank == 0:
                 print(f"\nCalculating shifts on region {self.regions[0]}...")
                 self.calculate_shifts(self.timepoints[0], self.regions[0])
             if world > 1:
                 row = sharding.shifts_to_row(self._shifts() if rank == 0 else None)
-                table = sharding.all_gather_shift_table(row[None], device=sharding.collective_device(self))
+                table = sharding.all_gather_shift_table(row[None], device=coll)
                 self._apply_shifts(sharding.first_valid(table))
         units = [(int(t), region) for t in self.timepoints for region in self.regions]
+        n_units = len(units)
         output_path = None
-        if world > 1 and len(units) < world and self.output_format.endswith('.zarr'):
+        shared = world > 1 and n_units < world and self.output_format.endswith('.zarr')
+        my_rows = {}      # unit index -> shift row measured by this rank (per-region registration)
+        if shared:
             # fewer (timepoint, region) units than GPUs: share each region by (channel, z) plane
             # instead -- every rank fuses its planes and writes their chunks into the common store
-            for timepoint, region in units:
+            for i, (timepoint, region) in enumerate(units):
+                if self.per_region_registration:
+                    if rank == 0:
+                        self.calculate_shifts(timepoint, region)
+                        my_rows[i] = sharding.shifts_to_row(self._shifts())
+                    row = my_rows.get(i, sharding.shifts_to_row(None))
+                    self._apply_shifts(sharding.first_valid(sharding.all_gather_shift_table(row[None], device=coll)))
                 output_path = self._run_region_by_planes(timepoint, region, rank, world)
             units = []
         for i in sharding.block_cyclic(len(units), rank, world):
@@ -815,6 +868,9 @@ class Stitcher:
             rtime = time.time()
             print(f"\nProcessing timepoint {timepoint}, region {region}" + (f" (rank {rank}/{world})" if world > 1 else ""))
             os.makedirs(os.path.join(self.output_folder, f"{timepoint}_stitched"), exist_ok=True)
+            if self.per_region_registration:
+                self.calculate_shifts(timepoint, region)
+                my_rows[i] = sharding.shifts_to_row(self._shifts())
             self.starting_stitching.emit()
             if self.output_format.endswith('.zarr'):
                 # fused planes stream to the store batch by batch; saving overlaps stitching
@@ -825,6 +881,8 @@ class Stitcher:
                 self.starting_saving.emit(False)
                 output_path = self.save_region_aics(timepoint, region, stitched_region)
             print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
+        if self.use_registration:
+            self._write_shift_table(n_units, my_rows, rank, world, coll)
         sharding.barrier()
         self.starting_saving.emit(True)
         if self.merge_timepoints or self.merge_hcs_regions:

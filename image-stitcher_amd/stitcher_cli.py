@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Command line of the stitcher: the reference's flags (stitcher_cli.py:14-62) unchanged,
-plus three switches for what this build adds (``--fusion-mode``, ``--normalization``,
-``--zarr-compression``).
+plus four switches for what this build adds (``--fusion-mode``, ``--normalization``,
+``--zarr-compression``, ``--per-region-registration``).
 
     python -m image_stitcher_amd.stitcher_cli -i /path/to/acquisition -r -ff --registration-channel "488"
 """
@@ -32,6 +32,8 @@ FLAGS = (
                                 help="cross-power normalisation: phase = scikit-image >= 0.19 default, none = 0.18 behaviour")),
     (('--zarr-compression',), dict(choices=['zlib', 'none'], default='zlib',
                                    help="OME-Zarr chunk compressor (none = raw chunks)")),
+    (('--per-region-registration',), dict(action='store_true',
+                                          help="with -r: register every (timepoint, region) on its own tiles instead of once")),
 )
 
 
@@ -81,7 +83,8 @@ def main(argv=None):
         params = create_params(args)
         stitcher = Stitcher(params, device=device, fusion_mode=args.fusion_mode,
                             normalization=None if args.normalization == 'none' else 'phase',
-                            zarr_compression=args.zarr_compression)
+                            zarr_compression=args.zarr_compression,
+                            per_region_registration=args.per_region_registration)
         print("Starting stitching with parameters:")
         for k, v in params.to_dict().items():
             print(f"{k}: {v}")

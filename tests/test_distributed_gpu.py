@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, root):
+def _worker(rank, world, port, root, extra=()):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SQ_DIST_BACKEND='gloo')
     from image_stitcher_amd import stitcher_cli
-    stitcher_cli.main(['-i', root, '-r', '--normalization', 'none'])
+    stitcher_cli.main(['-i', root, '-r', '--normalization', 'none', *extra])
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -36,6 +36,32 @@ def test_two_ranks_split_regions_and_agree_on_shifts(tmp_path):
     mp.spawn(_worker, args=(2, port, root), nprocs=2, join=True)
     outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
     assert len(outs) == 1, "both ranks must write into the folder rank 0 named"
+    for key in info['canvases']:
+        t, region = key[1:].split('_', 1)
+        store = os.path.join(tmp_path, outs[0], f'{t}_stitched', f'{region}_stitched.ome.zarr')
+        np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_per_region_registration_table_is_gathered(tmp_path, world):
+    """--per-region-registration: every rank registers the (t, region) units it owns, the rows are
+    all-gathered into shift_table.json (4 units over 2 ranks: even split; over 3 ranks: ragged, padded
+    rows must not leak into the table), and every store still equals the reference's canvas."""
+    import json
+    import torch.multiprocessing as mp
+    info, arrays = load_case('reg_multi')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(world, port, root, ('--per-region-registration',)), nprocs=world, join=True)
+    outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
+    assert len(outs) == 1
+    with open(os.path.join(tmp_path, outs[0], 'shift_table.json')) as fh:
+        table = json.load(fh)
+    assert table['per_region_registration'] is True
+    assert [(e['timepoint'], e['region']) for e in table['shifts']] == [(0, 'A1'), (0, 'B2'), (1, 'A1'), (1, 'B2')]
+    for e in table['shifts']:
+        assert (e['h_shift'], e['v_shift']) == (info['h_shift'], info['v_shift'])
     for key in info['canvases']:
         t, region = key[1:].split('_', 1)
         store = os.path.join(tmp_path, outs[0], f'{t}_stitched', f'{region}_stitched.ome.zarr')

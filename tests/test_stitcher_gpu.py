@@ -161,3 +161,24 @@ def test_dynamic_registration_all_pairs_survives_a_bad_centre_tile(tmp_path):
     write_tiff(path, np.full((spec.tile_h, spec.tile_w), 1234, dtype=np.uint16))
     assert shifts(False)[0] != golden[0]          # the reference's centre-pair scheme is derailed
     assert shifts(True) == dyn                    # the all-pairs median is not
+
+
+def test_run_writes_shift_table_single_process(tmp_path):
+    """run() leaves shift_table.json beside the stores: one entry per (timepoint, region) -- the shared
+    shifts of the reference's register-once scheme, or each unit's own with per_region_registration."""
+    import json
+    info, arrays = load_case('reg_multi')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    for per_region in (False, True):
+        st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None,
+                      per_region_registration=per_region)
+        st.run()
+        with open(os.path.join(st.output_folder, 'shift_table.json')) as fh:
+            table = json.load(fh)
+        assert table['per_region_registration'] is per_region and len(table['shifts']) == 4
+        assert all((e['h_shift'], e['v_shift']) == (info['h_shift'], info['v_shift']) for e in table['shifts'])
+        for key in info['canvases']:
+            t, region = key[1:].split('_', 1)
+            store = os.path.join(st.output_folder, f'{t}_stitched', f'{region}_stitched.ome.zarr')
+            np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
