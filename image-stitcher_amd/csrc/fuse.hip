@@ -15,7 +15,7 @@
 // canvas (its pitch is arbitrary, so the phase is recomputed per row); the tile side is read with
 // 16-byte loads at whatever 2-byte phase the placement leaves (measured cost: ~2 %).
 //
-// Measured on MI355X: 0.51-0.53 of the 8 TB/s HBM peak with float32 gains,
+// Measured on MI355X: 0.53-0.55 of the 8 TB/s HBM peak with float32 gains,
 // 0.58-0.63 without, 0.70 on one huge aligned tile (the ceiling of this structure).
 #include <hip/hip_runtime.h>
 
@@ -465,20 +465,10 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
 //   w_i = min(sx+1, W-sx, sy+1, H-sy) in the tile's own coordinates,
 //   v_i = tile / float32(flatfield) when a flatfield is given (no clip).
 //   integer canvases: rint + clip.  Uncovered voxels: 0.
-// Same skeleton as the overwrite kernel: persistent grid over (plane, item), one wave per canvas
-// row, 8 pixels per lane per step with stores aligned to the 8-pixel group, row edges one pixel
-// per lane.  The refs of an item are wave-uniform, so the per-ref loop runs on scalar registers.
+// Persistent grid over (plane, item) like the overwrite kernel.  Items with nothing to blend (no
+// tile, or one) go through the overwrite kernel's pipelined row copy; blended items deal their
+// (row, 8-pixel group) pairs to the workgroup's threads (blend_item / blend_group below).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int FLAT>
-__device__ __forceinline__ float feather_value(const FuseParams &P, const T *tile, const char *flat, int y, int x) {
-    float v = (float)ldg_s<T>(tile + (int64_t)y * P.tile_pitch + x);
-    if (FLAT && flat) {
-        const char *g = flat + ((int64_t)y * P.tile_w + x) * (FLAT == 2 ? 8 : 4);
-        v = __fdiv_rn(v, FLAT == 2 ? (float)ldg_s<double>(g) : ldg_s<float>(g));
-    }
-    return v;
-}
-
 template <typename OutT>
 __device__ __forceinline__ OutT feather_out(float o) {
     if (sizeof(OutT) == 4) return (OutT)o;
