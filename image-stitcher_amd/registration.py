@@ -96,6 +96,18 @@ def vertical_shift_from(shift: np.ndarray, n0: int) -> Tuple[int, int]:
     return round(shift[0] - n0), round(shift[1])
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for the second of two independent registration batches."""
+    import torch
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], ys: Sequence[float],
                          pixel_size_um: float, pixel_binning: int, normalization='phase',
                          scan_pattern: str = 'Unidirectional', tile_index=None) -> Shifts:
@@ -134,9 +146,27 @@ def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], y
                                               tile_ptrs=ptrs, shape=(height, width), np_dtype=np_dtype)
         return pending, n0, n1
 
-    # both batches are enqueued before the single synchronising fetch
-    hq = launch(hp, horizontal_pair) if hp else None
-    vq = launch(vp, vertical_pair) if vp else None
+    # Both batches are enqueued before the first synchronising fetch, the vertical one on a side
+    # stream: a batch of one or two pairs is a chain of small latency-bound kernels, and the two
+    # chains are independent, so they run side by side.
+    import torch
+    hq = vq = None
+    if hp and vp:
+        main = torch.cuda.current_stream(tiles.device)
+        side = _side_stream(tiles.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                       # pointer table and min/max are on the main stream
+        hq = launch(hp, horizontal_pair)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            vq = launch(vp, vertical_pair)
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(done)
+    elif hp:
+        hq = launch(hp, horizontal_pair)
+    elif vp:
+        vq = launch(vp, vertical_pair)
     if hq:
         s = shifts_from_results(hq[0].fetch(), 10)[0]
         out.h_shift = horizontal_shift_from(s[0], hq[2])
