@@ -79,18 +79,30 @@ static_assert(sizeof(Item) == 32, "Item layout");
 
 }  // namespace sq
 
-// TableHeader + spans + refs + items, exactly what goes to the device.  Plain malloc'd storage: the
-// builder writes every byte itself, so nothing is zero-filled first.
+// TableHeader + spans + refs + items, exactly what goes to the device.  The builder writes every byte
+// itself, so nothing is zero-filled first.  Storage is page-locked host memory when a device is
+// present (the upload is then one DMA at link speed instead of a staged pageable copy), taken from a
+// small pool so that building a plan per region does not page-lock memory each time; plain malloc
+// without a device (the CPU tests).
+void *sq_table_acquire(size_t bytes, size_t *capacity, bool *pinned);   // plan.cpp
+void sq_table_release(void *ptr, size_t capacity, bool pinned);
+
 struct sq_table {
     char *ptr = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, capacity = 0;
+    bool pinned = false;
     sq_table() = default;
     sq_table(const sq_table &) = delete;
     sq_table &operator=(const sq_table &) = delete;
-    ~sq_table() { free(ptr); }
+    ~sq_table() { reset(); }
+    void reset() {
+        if (ptr) sq_table_release(ptr, capacity, pinned);
+        ptr = nullptr;
+        bytes = capacity = 0;
+    }
     bool allocate(size_t n) {
-        free(ptr);
-        ptr = static_cast<char *>(malloc(n ? n : 1));
+        reset();
+        ptr = static_cast<char *>(sq_table_acquire(n ? n : 1, &capacity, &pinned));
         bytes = ptr ? n : 0;
         return ptr != nullptr;
     }

@@ -6,10 +6,13 @@
 // into intervals, give every interval its owner (overwrite: the last rect that covers it;
 // feather: all rects that cover it, in write order), merge equal neighbours horizontally and
 // then vertically.  The device then writes every canvas voxel exactly once.
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -32,6 +35,61 @@ struct Clipped {
 };
 
 }  // namespace
+
+// ---- storage pool of plan tables (see sq_table in common.h) ---------------------------------------
+namespace {
+struct TableSlab {
+    void *ptr;
+    size_t capacity;
+};
+std::mutex g_pool_mutex;
+std::vector<TableSlab> g_pool;          // page-locked slabs waiting for reuse
+constexpr size_t POOL_MAX_SLABS = 4;
+bool g_pinning_failed = false;          // no device / out of lockable memory: stop trying
+}   // namespace
+
+void *sq_table_acquire(size_t bytes, size_t *capacity, bool *pinned) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].capacity >= bytes && g_pool[i].capacity <= 2 * bytes + (1 << 20)) {
+                const TableSlab slab = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                *capacity = slab.capacity;
+                *pinned = true;
+                return slab.ptr;
+            }
+    }
+    if (!g_pinning_failed) {
+        const size_t cap = (bytes + (bytes >> 2) + 4095) & ~size_t(4095);   // 25 % headroom: the next region's plan fits too
+        void *p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) == hipSuccess && p) {
+            *capacity = cap;
+            *pinned = true;
+            return p;
+        }
+        (void)hipGetLastError();
+        g_pinning_failed = true;
+    }
+    *capacity = bytes;
+    *pinned = false;
+    return malloc(bytes);
+}
+
+void sq_table_release(void *ptr, size_t capacity, bool pinned) {
+    if (!pinned) {
+        free(ptr);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool.size() < POOL_MAX_SLABS) {
+            g_pool.push_back({ptr, capacity});
+            return;
+        }
+    }
+    (void)hipHostFree(ptr);
+}
 
 extern "C" {
 
@@ -341,6 +399,19 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 }
 
 void sq_fuse_plan_destroy(sq_fuse_plan *plan) { delete plan; }
+
+int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *stream_) {
+    if (!plan || !table_dev) return fail(SQ_ERR_INVALID, "sq_fuse_plan_upload: NULL argument");
+    if (table_bytes < (int64_t)plan->table.size())
+        return fail(SQ_ERR_INVALID, "sq_fuse_plan_upload: buffer %lld < table %zu bytes", (long long)table_bytes,
+                    plan->table.size());
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // returns when the copy is done: the plan may be destroyed (its storage recycled) right after
+    hipError_t e = hipMemcpyAsync(table_dev, plan->table.data(), plan->table.size(), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_plan_upload: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
 
 int64_t sq_fuse_plan_table_bytes(const sq_fuse_plan *plan) {
     if (!plan) return fail(SQ_ERR_INVALID, "sq_fuse_plan_table_bytes: NULL plan");

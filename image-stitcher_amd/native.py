@@ -66,6 +66,7 @@ EXPORTS = {
     'sq_fuse_plan_create': (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'sq_fuse_plan_destroy': (None, [C.c_void_p]),
     'sq_fuse_plan_table_bytes': (C.c_int64, [C.c_void_p]),
+    'sq_fuse_plan_upload': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'sq_fuse_plan_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     'sq_fuse_plan_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -168,9 +169,8 @@ class FusePlan:
                                         self.tile_h, self.tile_w, self.canvas_h, self.canvas_w, self.mode)
         if not self._h:
             raise NativeError(f"sq_fuse_plan_create failed: {L.sq_last_error().decode()}")
-        nbytes = L.sq_fuse_plan_table_bytes(self._h)
-        self.table = np.empty(nbytes, dtype=np.uint8)
-        _check(L.sq_fuse_plan_export(self._h, self.table.ctypes.data, nbytes), 'sq_fuse_plan_export')
+        self.table_bytes = int(L.sq_fuse_plan_table_bytes(self._h))
+        self._table = None
         ns, ni, cv, mr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         _check(L.sq_fuse_plan_stats(self._h, C.byref(ns), C.byref(ni), C.byref(cv), C.byref(mr)), 'sq_fuse_plan_stats')
         self.n_spans, self.n_items, self.covered_voxels, self.max_refs = ns.value, ni.value, cv.value, mr.value
@@ -180,11 +180,24 @@ class FusePlan:
     def handle(self) -> int:
         return self._h
 
+    @property
+    def table(self) -> np.ndarray:
+        """Host copy of the byte image the device reads (tests, inspection)."""
+        if self._table is None:
+            self._table = np.empty(self.table_bytes, dtype=np.uint8)
+            _check(lib().sq_fuse_plan_export(self._h, self._table.ctypes.data, self.table_bytes), 'sq_fuse_plan_export')
+        return self._table
+
     def device_table(self, device):
+        """The table in device memory, uploaded once per device (one DMA from the plan's page-locked
+        storage; sq_fuse_plan_upload waits for it, so the plan can be dropped at any time)."""
         import torch
         key = str(device)
         if key not in self._dev:
-            self._dev[key] = torch.from_numpy(self.table).to(device)
+            dev = torch.empty(max(self.table_bytes, 1), dtype=torch.uint8, device=device)
+            with torch.cuda.device(dev.device):
+                _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr()), 'sq_fuse_plan_upload')
+            self._dev[key] = dev
         return self._dev[key]
 
     def close(self) -> None:

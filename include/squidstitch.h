@@ -78,6 +78,12 @@ void sq_fuse_plan_destroy(sq_fuse_plan *plan);
  * (e.g. torch.from_numpy(...).cuda()) and passes the device copy to sq_fuse_planes. */
 int64_t sq_fuse_plan_table_bytes(const sq_fuse_plan *plan);
 int sq_fuse_plan_export(const sq_fuse_plan *plan, void *host_buf, int64_t host_bytes);
+
+/* Copy the table to caller-owned device memory (table_bytes >= sq_fuse_plan_table_bytes) on `stream`
+ * and wait for the copy: the plan may be destroyed right after.  The plan keeps its table in
+ * page-locked host memory when a device is present, so this is one DMA at link speed; prefer it to
+ * sq_fuse_plan_export + a copy of your own. */
+int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *stream);
 /* Introspection (tests, DESIGN.md numbers): n_spans, n_items, covered voxels, max tiles/span. */
 int sq_fuse_plan_stats(const sq_fuse_plan *plan, int64_t *n_spans, int64_t *n_items, int64_t *covered_voxels,
                        int32_t *max_refs);
