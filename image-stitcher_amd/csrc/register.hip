@@ -95,7 +95,7 @@ struct RegParams {
     sq_pair_result *results;
     char *ws;
     Layout L;
-    int32_t n_pairs, normalization, tc;
+    int32_t n_pairs, normalization, tc, rl_fwd, rl_inv;   // tc: columns per block (K2); rl_*: lines per block (K1, K3)
     int32_t n_tiles, tile_h, tile_w;
 };
 
@@ -318,20 +318,24 @@ __device__ __forceinline__ double normalised(const T *tile, int64_t idx, double 
     return q == q ? (double)(T)q : 0.0;
 }
 
+// One block = P.rl consecutive rows of one pair (as many as fit 64 KB of LDS, at most 8), sent through
+// the line FFT together: one barrier per pass for the batch, and eight times fewer, fuller blocks
+// than one row per block.
 template <typename T>
 __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n1 = L.n1, n1h = L.n1h;
-    cplx *x = reinterpret_cast<cplx *>(smem);
-    cplx *tmp = x + n1;
-    const int pair = blockIdx.y, r = blockIdx.x;
+    const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
+    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][n1]
+    cplx *tmp = x + (int64_t)rl * n1;              // [n1] (direct DFT only)
+    const int pair = blockIdx.y, r0 = blockIdx.x * rl;
+    const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
     const int tid = threadIdx.x, nt = blockDim.x;
-    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r * n1h;
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r0 * n1h;
     cplx *B = A + (int64_t)L.n0 * n1h;
     if (!pair_ok(P, pr)) {   // uniform per block
-        for (int k = tid; k < n1h; k += nt) A[k] = B[k] = {0.0, 0.0};
+        for (int e = tid; e < nrow * n1h; e += nt) A[e] = B[e] = {0.0, 0.0};
         return;
     }
     const T *ref = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.ref_tile])
@@ -340,17 +344,22 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
                                : static_cast<const T *>(P.tile_base) + pr.mov_tile * P.tile_stride;
     const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
     const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
-    const int64_t rbase = (int64_t)(pr.ref_y0 + r) * P.tile_pitch + pr.ref_x0;
-    const int64_t mbase = (int64_t)(pr.mov_y0 + r) * P.tile_pitch + pr.mov_x0;
-    for (int j = tid; j < n1; j += nt) x[j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+    for (int e = tid; e < nrow * n1; e += nt) {
+        const int l = e / n1, j = e - l * n1;
+        const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
+        const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
+        x[e] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+    }
     __syncthreads();
-    line_fft<false>(x, tmp, n1, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
-    for (int k = tid; k < n1h; k += nt) {
-        const cplx zk = x[k], zc = cconj(x[k ? n1 - k : 0]);
+    lines_fft<false>(x, tmp, n1, nrow, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    for (int e = tid; e < nrow * n1h; e += nt) {
+        const int l = e / n1h, k = e - l * n1h;
+        const cplx *xl = x + (int64_t)l * n1;
+        const cplx zk = xl[k], zc = cconj(xl[k ? n1 - k : 0]);
         // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
-        A[k] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
+        A[e] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
         const cplx d = {zk.re - zc.re, zk.im - zc.im};
-        B[k] = {0.5 * d.im, -0.5 * d.re};
+        B[e] = {0.5 * d.im, -0.5 * d.re};
     }
 }
 
@@ -475,19 +484,36 @@ __device__ Best block_best(Best b, int tid, int nt) {
     return r;
 }
 
+// One block = P.rl row pairs (lines) of one pair; the lines go through the FFT together, then every
+// wave scans whole lines for their maximum (shuffles only, no block reduction) and writes one
+// (value, index) per row pair, which K4a reduces.
+__device__ __forceinline__ Best wave_best(Best b) {
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(b.v, off);
+        o.idx = __shfl_xor(b.idx, off);
+        o.nan = __shfl_xor(b.nan, off);
+        b = better(b, o);
+    }
+    return b;
+}
+
 __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h;
-    cplx *x = reinterpret_cast<cplx *>(smem);
-    cplx *tmp = x + n1;
-    const int pair = blockIdx.y, rp = blockIdx.x;
-    const int y0 = 2 * rp, y1 = min(2 * rp + 1, n0 - 1);   // odd n0: the last block repeats its row
-    const bool two = (2 * rp + 1) < n0;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
+    const int nrp = (n0 + 1) / 2;
+    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][n1]
+    cplx *tmp = x + (int64_t)rl * n1;
+    const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
+    const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
     const cplx *Q = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
-    const cplx *q0 = Q + (int64_t)y0 * n1h, *q1 = Q + (int64_t)y1 * n1h;
-    for (int k = tid; k < n1; k += nt) {
+    for (int e = tid; e < nline * n1; e += nt) {
+        const int l = e / n1, k = e - l * n1;
+        const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);   // odd n0: the last line repeats its row
+        const bool two = (y0 + 1) < n0;
+        const cplx *q0 = Q + (int64_t)y0 * n1h, *q1 = Q + (int64_t)y1 * n1h;
         // Hermitian extension of the half spectrum of a real row: X[n1-k] = conj X[k]
         cplx a, b;
         if (k < n1h) {
@@ -498,20 +524,26 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
             b = cconj(q1[n1 - k]);
         }
         if (!two) b = {0.0, 0.0};
-        x[k] = {a.re - b.im, a.im + b.re};   // a + i b
+        x[e] = {a.re - b.im, a.im + b.re};   // a + i b
     }
     __syncthreads();
-    line_fft<true>(x, tmp, n1, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
-    Best best = {-1.0, (long long)1 << 62, 0};
-    for (int k = tid; k < n1; k += nt) {
-        best = better(best, make_best(fabs(x[k].re), (long long)y0 * n1 + k));
-        if (two) best = better(best, make_best(fabs(x[k].im), (long long)y1 * n1 + k));
-    }
-    best = block_best(best, tid, nt);
-    if (tid == 0) {
-        double *out = reinterpret_cast<double *>(P.ws + L.rowmax) + ((int64_t)pair * ((n0 + 1) / 2) + rp) * 2;
-        out[0] = best.v;   // NaN stays NaN
-        reinterpret_cast<long long *>(out)[1] = best.idx;
+    lines_fft<true>(x, tmp, n1, nline, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    for (int l = wave; l < nline; l += nw) {
+        const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);
+        const bool two = (y0 + 1) < n0;
+        const cplx *xl = x + (int64_t)l * n1;
+        Best best = {-1.0, (long long)1 << 62, 0};
+        for (int k = lane; k < n1; k += 64) {
+            best = better(best, make_best(fabs(xl[k].re), (long long)y0 * n1 + k));
+            if (two) best = better(best, make_best(fabs(xl[k].im), (long long)y1 * n1 + k));
+        }
+        best = wave_best(best);
+        if (lane == 0) {
+            double *out = reinterpret_cast<double *>(P.ws + L.rowmax) + ((int64_t)pair * nrp + rp0 + l) * 2;
+            out[0] = best.v;   // NaN stays NaN
+            reinterpret_cast<long long *>(out)[1] = best.idx;
+        }
     }
 }
 
@@ -848,12 +880,27 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
 
     hipLaunchKernelGGL(init_tables_kernel, dim3(64), dim3(256), 0, s, P);
-    const size_t lds_row = (size_t)2 * L.n1 * 16;
-    const int nt1 = pick_threads(L.n1);
+    // Lines per block of the row kernels, measured on 240-pair batches: the forward kernel (global loads
+    // + a float64 normalisation per pixel) likes many small blocks -- 16 KB of lines; the inverse kernel
+    // (LDS FFT + a per-wave argmax) likes up to 8 lines within 64 KB.  Never more than keeps ~2 blocks
+    // per CU busy when the batch is small (the bench's single centre pairs).
+    const int64_t line_bytes = (int64_t)L.n1 * 16;
+    const int64_t dft_scratch = is_pow2(L.n1) ? 0 : line_bytes;
+    auto lines_per_block = [&](int cap, int n_lines) {
+        int rl = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (64 * 1024 - dft_scratch) / line_bytes));
+        while (rl > 1 && (int64_t)a->n_pairs * ((n_lines + rl - 1) / rl) < 512) rl >>= 1;
+        return rl;
+    };
+    const int rlf = lines_per_block((int)std::max<int64_t>(1, std::min<int64_t>(8, 16384 / line_bytes)), L.n0);
+    const int rli = lines_per_block(8, (L.n0 + 1) / 2);
+    P.rl_fwd = rlf;
+    P.rl_inv = rli;
+    const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
+    const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
     if (a->tile_dtype == SQ_U16)
-        hipLaunchKernelGGL(rows_forward_kernel<uint16_t>, dim3(L.n0, a->n_pairs), dim3(nt1), lds_row, s, P);
+        hipLaunchKernelGGL(rows_forward_kernel<uint16_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
     else
-        hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3(L.n0, a->n_pairs), dim3(nt1), lds_row, s, P);
+        hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
     const size_t lds_col = ((size_t)2 * tc + 1) * L.n0 * 16;
     if (lds_col > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(columns_kernel),
@@ -861,7 +908,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
-    hipLaunchKernelGGL(rows_inverse_kernel, dim3((L.n0 + 1) / 2, a->n_pairs), dim3(nt1), lds_row, s, P);
+    hipLaunchKernelGGL(rows_inverse_kernel, dim3(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs), dim3(nti), lds_inv, s, P);
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
         if ((int64_t)a->n_pairs * ((L.n0 + 127) / 128) >= 256)
