@@ -447,41 +447,69 @@ class Stitcher:
         return canvas[0].cpu().numpy()
 
     def get_flatfields(self, progress_callback=None):
-        """The reference fits BaSiC on <= 48 random tiles per channel (stitcher.py:365-419).
-        basicpy/jax are absent offline, so the estimate here is a documented stand-in, NOT a
-        restatement (parity unpinned): per-channel mean of the sampled tiles,
-        box-smoothed, normalised to mean 1.  Flatfields assigned to ``self.flatfields`` by the
-        caller are left untouched."""
-        for channel in self.channel_names:
-            if self.monochrome_channels.count(channel) != 1:
-                continue
-            channel_index = self.monochrome_channels.index(channel)
+        """One gain image per monochrome channel from <= 48 randomly chosen tiles (stitcher.py:365-419).
+
+        The reference fits BaSiC (``basicpy``, a third-party estimator: iterative low-rank / sparse fit on
+        jax) -- when that package is importable the very same call is made here,
+        ``BaSiC(get_darkfield=False, smoothness_flatfield=1).fit(images).flatfield``, so the gains are the
+        reference's.  basicpy and jax are absent offline; without them the estimate is a documented
+        stand-in, NOT a restatement (parity unpinned): per-channel mean of the sampled
+        tiles, box-smoothed, normalised to mean 1.  Either way the estimate is not on the hot path: the
+        divide by the gains is (``apply_flatfield_correction``, in the fusion kernel).  Flatfields already
+        assigned to ``self.flatfields`` are left untouched."""
+        try:
+            from basicpy import BaSiC
+        except Exception:
+            BaSiC = None
+            print("[flatfield] basicpy is not installed: using the mean / box-smooth stand-in estimate "
+                  "(the reference fits BaSiC; assign Stitcher.flatfields to supply your own gains)")
+
+        def estimate(images: np.ndarray, channel_name: str):
+            channel_index = self.monochrome_channels.index(channel_name)
             if channel_index in self.flatfields:
-                continue
-            print(f"[flatfield] estimating {channel}")
-            images = []
-            for t in self.timepoints:
-                paths = [v['filepath'] for k, v in self.acquisition_metadata.items()
-                         if v['channel'] == channel and k[0] == int(t)]
-                random.shuffle(paths)
-                images.extend(paths[:min(32, len(paths))])
-                if len(images) > 48:
-                    break
-            if not images:
-                print(f"WARNING: No images found for channel {channel} across all timepoints")
-                continue
-            acc = np.zeros((self.input_height, self.input_width), dtype=np.float64)
-            for p in images:
-                acc += read_image(p)
-            acc /= len(images)
-            k = max(1, min(self.input_height, self.input_width) // 16)
-            csum = np.cumsum(np.cumsum(np.pad(acc, ((k, k), (k, k)), mode='edge'), 0), 1)
-            csum = np.pad(csum, ((1, 0), (1, 0)))
-            n = 2 * k + 1
-            smooth = (csum[n:, n:] - csum[:-n, n:] - csum[n:, :-n] + csum[:-n, :-n]) / (n * n)
-            self.flatfields[channel_index] = (smooth / smooth.mean()).astype(np.float32)
+                return
+            if BaSiC is not None:
+                basic = BaSiC(get_darkfield=False, smoothness_flatfield=1)
+                basic.fit(images)
+                self.flatfields[channel_index] = np.asarray(basic.flatfield)
+            else:
+                acc = images.astype(np.float64).mean(axis=0)
+                k = max(1, min(acc.shape) // 16)
+                csum = np.cumsum(np.cumsum(np.pad(acc, ((k, k), (k, k)), mode='edge'), 0), 1)
+                csum = np.pad(csum, ((1, 0), (1, 0)))
+                n = 2 * k + 1
+                smooth = (csum[n:, n:] - csum[:-n, n:] - csum[n:, :-n] + csum[:-n, :-n]) / (n * n)
+                self.flatfields[channel_index] = (smooth / smooth.mean()).astype(np.float32)
             if progress_callback:
                 progress_callback(channel_index + 1, self.num_c)
+
+        for channel in self.channel_names:
+            print(f"Calculating {channel} flatfield...")
+            paths = []
+            for t in self.timepoints:
+                at_t = [v['filepath'] for k, v in self.acquisition_metadata.items()
+                        if v['channel'] == channel and k[0] == int(t)]
+                if not at_t:
+                    print(f"WARNING: No images found for channel {channel} at timepoint {t}")
+                    continue
+                random.shuffle(at_t)
+                paths.extend(at_t[:min(32, len(at_t))])
+                if len(paths) > 48:
+                    break
+            if not paths:
+                print(f"WARNING: No images found for channel {channel} across all timepoints")
+                continue
+            images = np.array([read_image(p) for p in paths])
+            if images.ndim == 4 and images.shape[1] == 1:       # (N, 1, Y, X) page stacks
+                images = images[:, 0]
+            if images.ndim == 3:
+                estimate(images, channel)
+            elif images.ndim == 4 and images.shape[-1] == 3:    # RGB files: one gain image per colour
+                base = channel.split('_')[0]
+                for i, color in enumerate('RGB'):
+                    estimate(images[..., i], f"{base}_{color}")
+            else:
+                raise ValueError(f"Unexpected number of dimensions in images array: {images.ndim}")
 
     # ----------------------------------------------------------------- fusion
     def _keep_buffers(self, key, bufs) -> None:

@@ -206,3 +206,46 @@ def test_grid_rects_vectorised_equals_per_tile_formula():
                 want = np.array([placement.registered_rect(r, c, n_rows, n_cols, w, h, sh, crop)
                                  for r, c in (od or [(r, c) for r in range(n_rows) for c in range(n_cols)])])
                 np.testing.assert_array_equal(placement.grid_rects(n_rows, n_cols, w, h, sh, od, crop), want.reshape(-1, 6))
+
+
+def test_get_flatfields_standin_and_basicpy_delegation(tmp_path, monkeypatch):
+    """Flatfield *estimation* (stitcher.py:365-419) is host-side and off the hot path: with basicpy present
+    the reference's own call is made; without it a stand-in estimate is used.  uint8 acquisition with an RGB
+    channel: one gain image per monochrome channel."""
+    import sys
+    import types
+    from image_stitcher_amd.stitcher import Stitcher
+    spec = synth.GridSpec(rows=2, cols=3, tile_h=32, tile_w=48, ov_y=8, ov_x=8, seed=3, dtype='uint8',
+                          channels=('BF LED matrix full_RGB', 'Fluorescence 488 nm Ex'), rgb_channels=('BF LED matrix full_RGB',))
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+
+    def prepared():
+        st = Stitcher(StitchingParameters(input_folder=root, apply_flatfield=True))
+        st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+        return st
+
+    monkeypatch.setitem(sys.modules, 'basicpy', None)            # import fails -> stand-in
+    st = prepared()
+    seen = []
+    st.get_flatfields(progress_callback=lambda i, n: seen.append((i, n)))
+    assert sorted(st.flatfields) == list(range(st.num_c)) == [0, 1, 2, 3] and len(seen) == 4
+    for ff in st.flatfields.values():
+        assert ff.shape == (32, 48) and ff.dtype == np.float32 and abs(float(ff.mean()) - 1.0) < 1e-5
+
+    calls = []
+
+    class FakeBaSiC:
+        def __init__(self, **kw):
+            calls.append(kw)
+
+        def fit(self, images):
+            assert images.ndim == 3 and images.shape[1:] == (32, 48)
+            self.flatfield = np.full(images.shape[1:], 1.25, dtype=np.float64)
+
+    monkeypatch.setitem(sys.modules, 'basicpy', types.SimpleNamespace(BaSiC=FakeBaSiC))
+    st = prepared()
+    st.flatfields[3] = np.ones((32, 48), np.float32)             # supplied by the caller: left alone
+    st.get_flatfields()
+    assert calls == [dict(get_darkfield=False, smoothness_flatfield=1)] * 3
+    assert all(float(st.flatfields[i][0, 0]) == 1.25 for i in range(3)) and float(st.flatfields[3][0, 0]) == 1.0
