@@ -68,7 +68,8 @@ def test_per_region_registration_table_is_gathered(tmp_path, world):
         np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
 
 
-def test_two_ranks_share_one_region_by_planes(tmp_path):
+@pytest.mark.parametrize('per_region', [False, True])
+def test_two_ranks_share_one_region_by_planes(tmp_path, per_region):
     """One region, one timepoint, 2 channels x 2 z = 4 planes: with more GPUs than (t, region) units the
     ranks split the planes and write the chunks of their planes into the same OME-Zarr store."""
     import torch.multiprocessing as mp
@@ -76,20 +77,25 @@ def test_two_ranks_share_one_region_by_planes(tmp_path):
     root = str(tmp_path / 'acq')
     synth.write_acquisition(spec_of(info), root)
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker_planes, args=(2, port, root, info['params']['registration_channel']), nprocs=2, join=True)
+    mp.spawn(_worker_planes, args=(2, port, root, info['params']['registration_channel'], per_region), nprocs=2, join=True)
     outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
     assert len(outs) == 1
     store = os.path.join(tmp_path, outs[0], '0_stitched', 'R0_stitched.ome.zarr')
     np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays['t0_R0_canvas'])
     assert not os.path.exists(os.path.join(store, '1'))      # num_pyramid_levels is 1 for this small canvas
+    import json
+    with open(os.path.join(tmp_path, outs[0], 'shift_table.json')) as fh:
+        table = json.load(fh)
+    assert table['per_region_registration'] is per_region and len(table['shifts']) == 1
+    assert (table['shifts'][0]['h_shift'], table['shifts'][0]['v_shift']) == (info['h_shift'], info['v_shift'])
 
 
-def _worker_planes(rank, world, port, root, channel):
+def _worker_planes(rank, world, port, root, channel, per_region=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SQ_DIST_BACKEND='gloo')
     from image_stitcher_amd import stitcher_cli
     stitcher_cli.main(['-i', root, '-r', '--registration-channel', channel, '--registration-z-level', '1',
-                       '--normalization', 'none'])
+                       '--normalization', 'none'] + (['--per-region-registration'] if per_region else []))
     import torch.distributed as dist
     dist.destroy_process_group()
