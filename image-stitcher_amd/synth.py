@@ -208,3 +208,47 @@ def write_acquisition(spec: GridSpec, root: str) -> List[str]:
         with open(os.path.join(tdir, 'coordinates.csv'), 'w') as fh:
             fh.write('\n'.join(lines) + '\n')
     return paths
+
+
+def write_acquisition_device(spec: GridSpec, root: str, device, workers: int = 16) -> List[str]:
+    """``write_acquisition`` for big grids: tiles come from the device generator (sq_synth_tiles, bit for bit
+    the numpy generator above) one (t, region, z, channel) plane at a time and are written by a thread
+    pool.  Monochrome channels only.  Test / tool helper: needs the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import native
+    if spec.rgb_channels:
+        raise ValueError("write_acquisition_device writes monochrome channels only")
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, 'acquisition parameters.json'), 'w') as fh:
+        json.dump(spec.acquisition_parameters(), fh, indent=2)
+    missing = set(map(tuple, spec.missing))
+    paths = []
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for t in range(spec.nt):
+            tdir = os.path.join(root, str(t))
+            os.makedirs(tdir, exist_ok=True)
+            lines = ['region,fov,z_level,x (mm),y (mm),z (um)']
+            for ri, region in enumerate(spec.regions):
+                cells = [(r, c, spec.fov_index(r, c)) for r in range(spec.rows) for c in range(spec.cols)]
+                for r, c, fov in cells:
+                    x_mm, y_mm = spec.stage_mm(r, c)
+                    for z in range(spec.nz):
+                        lines.append(f'{region},{fov},{z},{x_mm!r},{y_mm!r},{z * spec.dz_um!r}')
+                for z in range(spec.nz):
+                    for ci, ch in enumerate(spec.channels):
+                        desc = np.zeros(len(cells), dtype=native.SYNTH_DTYPE)
+                        for i, (r, c, fov) in enumerate(cells):
+                            oy, ox = spec.origin(r, c)
+                            desc[i] = (spec.scene_seed(ri, t, z, ci) % 2 ** 64, spec.noise_seed(ri, t, z, ci, fov) % 2 ** 64, oy, ox)
+                        plane = native.synth_tiles(desc, spec.tile_h, spec.tile_w, spec.noise, spec.dtype, device).cpu().numpy()
+                        jobs = []
+                        for i, (r, c, fov) in enumerate(cells):
+                            if (fov, z, ci, t) in missing:
+                                continue
+                            p = os.path.join(tdir, f'{region}_{fov}_{z}_{channel_file_token(ch)}.tiff')
+                            jobs.append((p, plane[i]))
+                            paths.append(p)
+                        list(pool.map(lambda job: write_tiff(*job), jobs))
+            with open(os.path.join(tdir, 'coordinates.csv'), 'w') as fh:
+                fh.write('\n'.join(lines) + '\n')
+    return paths

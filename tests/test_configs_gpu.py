@@ -1,9 +1,11 @@
 """BASELINE.json's configurations as parity cases (scaled where the full size would not finish in
 seconds on the oracle), plus size-independent properties at the full tile size."""
+import os
+
 import numpy as np
 import pytest
 
-from image_stitcher_amd import native, placement, registration, sharding, synth
+from image_stitcher_amd import native, omezarr, placement, registration, sharding, synth
 from image_stitcher_amd.stitcher import Stitcher
 from image_stitcher_amd.stitcher_parameters import StitchingParameters
 from image_stitcher_amd.tiffio import read_image
@@ -113,3 +115,35 @@ def test_config5_hcs_plate_scaled(tmp_path):
             canvas = st.stitch_region(int(t), well)
             np.testing.assert_array_equal(canvas, O.stitch_region(acq, t, well, read_image, True, want))
     assert np.stack(table).shape == (6, sharding.SHIFT_ROW)
+
+
+def test_config3_planes_from_files_to_store_at_full_size(tmp_path):
+    """BASELINE config 3 end to end at full tile and grid size, cut to one channel x two z planes: 512
+    files of 2048^2 -> CLI (-r -ff semantics with supplied gains) -> streamed multiscale OME-Zarr store.
+    Level 0 equals the oracle's canvas plane by plane (the oracle itself reproduces the genuine reference
+    on exactly this configuration), the pyramid levels are the strided gathers of it."""
+    import torch
+    dev = torch.device('cuda:0')
+    spec = synth.GridSpec(rows=16, cols=16, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, seed=3000, nz=2)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition_device(spec, root, dev)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, apply_flatfield=True), normalization='phase',
+                  zarr_compression='none')
+    st.output_folder = str(tmp_path / 'out')
+    st.batch_bytes_limit = 256 * 2048 * 2048 * 2          # one plane per batch: both writer slots are used
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    flat = synth.synthetic_flatfield(2048, 2048, np.float32)
+    st.flatfields = {0: flat}
+    st.calculate_shifts(0, 'R0')
+    assert (st.h_shift, st.v_shift) == ((3, -244), (-244, -2))
+    path = st.stream_region_to_zarr(0, 'R0')
+    assert st.num_pyramid_levels == 6
+    acq = O.parse_acquisition(root, read_image)
+    shifts = {'h_shift': st.h_shift, 'v_shift': st.v_shift}
+    want = O.stitch_region(acq, 0, 'R0', read_image, True, shifts, {0: flat}, True)
+    assert want.shape == (1, 1, 2, 36473, 29138)
+    got = omezarr.read_array(os.path.join(path, '0'))
+    np.testing.assert_array_equal(got, want)
+    for lv, lvl in enumerate(O.pyramid_nearest(want, 6)):
+        if lv:
+            np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, str(lv))), lvl)
