@@ -41,7 +41,8 @@ def stream_vs_sequential(spec, batch_bytes):
     tmp = tempfile.mkdtemp(prefix='e2e_', dir=os.environ.get('TMPDIR', '/tmp'))
     try:
         root = os.path.join(tmp, 'acq')
-        t0 = time.time(); synth.write_acquisition(spec, root); t_write = time.time() - t0
+        import torch
+        t0 = time.time(); synth.write_acquisition_device(spec, root, torch.device('cuda:0')); t_write = time.time() - t0
         print(f'stream probe: {spec.rows}x{spec.cols} x {spec.tile_h}^2, {len(spec.channels)} ch x {spec.nz} z; tiles written in {t_write:.1f}s', flush=True)
         for compression in ('zlib', 'none'):
             for mode in ('sequential', 'streamed'):
@@ -71,4 +72,4 @@ def stream_vs_sequential(spec, batch_bytes):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-stream_vs_sequential(G(rows=6, cols=6, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, seed=2500, nz=6), batch_bytes=2 * 36 * 2048 * 2048 * 2)
+stream_vs_sequential(G(rows=16, cols=16, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, seed=2500, nz=4), batch_bytes=256 * 2048 * 2048 * 2)
