@@ -46,7 +46,7 @@ struct TableHeader {
     int64_t n_spans, n_refs, n_items;
     int64_t off_spans, off_refs, off_items;  // byte offsets from the table start
     int64_t covered_voxels;
-    int64_t reserved;
+    int64_t lane_items;   // list positions [0, 8 * lane_items) are lane-interleaved: position = rank * 8 + lane (else 0)
 };
 static_assert(sizeof(TableHeader) == 96, "TableHeader layout");
 

@@ -73,7 +73,12 @@ struct FuseParams {
     int32_t n_tiles, tile_h, tile_w, tile_pitch;
     int32_t canvas_pitch;
     const uint32_t *flat_class;   // per plane: 0 = every gain is a normal float (fast divide allowed)
+    uint32_t *queue;              // 9 chunk counters (8 XCD lanes + the rest), one 128-byte line each; NULL = static stride
+    int32_t lane_items;           // list positions [0, 8 * lane_items) of a plane are lane-interleaved
+    int32_t n_planes;
 };
+constexpr int QUEUE_STRIDE = 32;   // uint32 words between the counters
+constexpr int QUEUE_CHUNK = 8;     // consecutive lane positions a workgroup takes per atomic
 
 template <typename T>
 __device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int tile) {
@@ -418,42 +423,133 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
     }
 }
 
-// Work distribution: a persistent grid-stride walk.  Tried and rejected (measured): nine device
-// counters (one per XCD lane of the item list + leftovers) pulled with atomicAdd by workgroups that
-// read the XCD they really run on (HW_REG_XCC_ID).  It pins every XCD to one contiguous window of
-// its lane -- rocprofv3 FETCH_SIZE fell from 57.8e6 KB to 35.8e6 KB per launch, i.e. the flatfield
-// was fetched exactly once -- but the per-item barrier + atomic cost more than the L2 misses it
-// removed (they are served by the Infinity Cache): 3320 vs 3594 GB/s on the same box.
-template <typename T, int FLAT>
+// Work distribution.
+//  * static (no scratch given): a persistent grid-stride walk, block b takes items b, b + G, ...
+//  * dynamic: per plane the item list is 8 interleaved lanes (one per XCD: lane x holds the items of the
+//    tile-row blocks == x mod 8, see plan.cpp) followed by a short rest.  Nine device counters hand out
+//    chunks of QUEUE_CHUNK consecutive positions of a lane; a workgroup reads the XCD it really runs on
+//    (HW_REG_XCC_ID), pulls from THAT lane, and moves on to the next lane / the rest once its own is
+//    drained.  The items in flight on an XCD are then always one contiguous window of its lane -- same
+//    flatfield rows, fetched into that XCD's L2 once, however unevenly workgroups progress (with the
+//    static stride they drift apart over a 35 ms launch: PMC, 52 GB of gains re-fetched per launch)
+//    -- and the launch ends with every workgroup busy.  One atomic and one barrier per chunk (the
+//    first attempt paid both per item and lost 7 %); the atomic for the next chunk is issued before
+//    the current chunk is processed and its result only looked at afterwards.
+struct Chunk {
+    int q;         // 0..7 lane, 8 rest, -1 none
+    uint32_t c;    // chunk index inside the queue
+};
+
+// wave-uniform values the compiler cannot prove uniform (they come out of LDS): pin them to scalar registers
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ Item sgpr(Item it) {
+    it.dst_y = sgpr(it.dst_y);
+    it.dst_x = sgpr(it.dst_x);
+    it.hw = sgpr(it.hw);
+    it.nref = sgpr(it.nref);
+    it.a = sgpr(it.a);
+    it.b = sgpr(it.b);
+    it.c = sgpr(it.c);
+    it.span = sgpr(it.span);
+    return it;
+}
+template <typename T>
+__device__ __forceinline__ const T *sgpr(const T *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)sgpr((int)(uint32_t)v), hi = (uint32_t)sgpr((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
+}
+
+template <typename T, int FLAT, bool DYN>
 __global__ __launch_bounds__(256, (FLAT == 1 ? (sizeof(T) == 2 ? SQ_WAVES_F32 : 1) : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
 void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
-    // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
-    // pointer are fetched while the current item streams
-    int64_t work = blockIdx.x;
-    if (work >= n_work) return;
-    int plane = (int)(work / n_items);
-    Item it = P.items[work - plane * n_items];
-    const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
-    while (true) {
-        const int64_t nwork = work + gridDim.x;
-        const bool more = nwork < n_work;
-        int nplane = plane;
-        Item nit = it;
-        const T *ntile = nullptr;
-        if (more) {
-            nplane = (int)(nwork / n_items);
-            nit = P.items[nwork - nplane * n_items];
-            ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
+    if (!DYN) {
+        // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
+        // pointer are fetched while the current item streams
+        int64_t work = blockIdx.x;
+        if (work >= n_work) return;
+        int plane = (int)(work / n_items);
+        Item it = P.items[work - plane * n_items];
+        const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+        while (true) {
+            const int64_t nwork = work + gridDim.x;
+            const bool more = nwork < n_work;
+            int nplane = plane;
+            Item nit = it;
+            const T *ntile = nullptr;
+            if (more) {
+                nplane = (int)(nwork / n_items);
+                nit = P.items[nwork - nplane * n_items];
+                ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
+            }
+            process_item<T, FLAT>(P, plane, it, tile, wave, lane);
+            if (!more) break;
+            work = nwork;
+            plane = nplane;
+            it = nit;
+            tile = ntile;
         }
-        process_item<T, FLAT>(P, plane, it, tile, wave, lane);
-        if (!more) break;
-        work = nwork;
-        plane = nplane;
-        it = nit;
-        tile = ntile;
+        return;
+    }
+
+    // ---- dynamic: chunked per-XCD queues -------------------------------------------------------
+    __shared__ int s_q[2];
+    __shared__ uint32_t s_c[2];
+    __shared__ Item s_item[QUEUE_CHUNK];          // the chunk's descriptors, loaded by QUEUE_CHUNK threads at once
+    __shared__ const T *s_tile[QUEUE_CHUNK];
+    __shared__ int s_plane[QUEUE_CHUNK];
+    const int home = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // HW_REG_XCC_ID[3:0]
+    // queue q holds n_planes * per_plane(q) positions; 32-bit arithmetic (the host checks the sizes)
+    auto per_plane_of = [&](int q) { return (uint32_t)(q < 8 ? (int64_t)P.lane_items : n_items - 8 * (int64_t)P.lane_items); };
+    auto total_of = [&](int q) { return (uint32_t)P.n_planes * per_plane_of(q); };
+    int given_up = 0;   // thread 0: queues found empty so far (own lane first, then the others, then the rest)
+    auto queue_of = [&](int k) { return k < 8 ? ((home + k) & 7) : 8; };
+    auto settle = [&](uint32_t c) -> Chunk {   // thread 0: make (given_up, c) a real chunk or move on
+        while (true) {
+            const int q = queue_of(given_up);
+            if ((uint64_t)c * QUEUE_CHUNK < total_of(q)) return {q, c};
+            if (++given_up > 8) return {-1, 0u};
+            c = atomicAdd(&P.queue[queue_of(given_up) * QUEUE_STRIDE], 1u);
+        }
+    };
+    if (threadIdx.x == 0) {
+        const Chunk first = settle(atomicAdd(&P.queue[queue_of(0) * QUEUE_STRIDE], 1u));
+        s_q[0] = first.q;
+        s_c[0] = first.c;
+    }
+    for (int iter = 0;; ++iter) {
+        __syncthreads();
+        const int q = sgpr(s_q[iter & 1]);
+        if (q < 0) break;
+        const uint32_t c = (uint32_t)sgpr((int)s_c[iter & 1]);
+        uint32_t pending = 0;
+        const bool pull = threadIdx.x == 0 && given_up <= 8;
+        if (pull) pending = atomicAdd(&P.queue[queue_of(given_up) * QUEUE_STRIDE], 1u);   // next chunk; looked at after this one
+        const uint32_t u0 = c * (uint32_t)QUEUE_CHUNK;
+        const int count = (int)min((uint32_t)QUEUE_CHUNK, total_of(q) - u0);
+        if ((int)threadIdx.x < count) {   // one descriptor per thread: queue position -> (plane, list position)
+            const uint32_t per_plane = per_plane_of(q);
+            const uint32_t u = u0 + threadIdx.x;
+            const int plane = (int)(u / per_plane);
+            const uint32_t r = u - (uint32_t)plane * per_plane;
+            const Item it = P.items[q < 8 ? (int64_t)r * 8 + q : 8 * (int64_t)P.lane_items + r];
+            s_item[threadIdx.x] = it;
+            s_plane[threadIdx.x] = plane;
+            s_tile[threadIdx.x] = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+        }
+        __syncthreads();
+        for (int j = 0; j < count; ++j) {
+            const Item it = sgpr(s_item[j]);
+            process_item<T, FLAT>(P, sgpr(s_plane[j]), it, sgpr(s_tile[j]), wave, lane);
+        }
+        if (threadIdx.x == 0) {
+            const Chunk nxt = pull ? settle(pending) : Chunk{-1, 0u};
+            s_q[(iter + 1) & 1] = nxt.q;
+            s_c[(iter + 1) & 1] = nxt.c;
+        }
     }
 }
 
@@ -760,7 +856,8 @@ extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int3
 
 extern "C" int64_t sq_fuse_scratch_bytes(int32_t n_planes) {
     if (n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_scratch_bytes: n_planes %d", n_planes);
-    return ((int64_t)n_planes * 4 + 15) & ~int64_t(15);   // one uint32 gain class per plane
+    // one uint32 gain class per plane, then the nine chunk counters of the work queues, a 128-byte line each
+    return (((int64_t)n_planes * 4 + 127) & ~int64_t(127)) + 9 * QUEUE_STRIDE * 4;
 }
 
 extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
@@ -811,17 +908,25 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.flat_class = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
-    if (flat == 1 && a->scratch_dev && a->n_planes > 0) {
-        // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
+    P.queue = nullptr;
+    P.lane_items = (int32_t)h.lane_items;
+    P.n_planes = a->n_planes;
+    if (a->scratch_dev && a->n_planes > 0) {
         if (a->scratch_bytes < sq_fuse_scratch_bytes(a->n_planes))
             return fail(SQ_ERR_WORKSPACE, "sq_fuse_planes: scratch %lld < %lld bytes", (long long)a->scratch_bytes,
                         (long long)sq_fuse_scratch_bytes(a->n_planes));
-        if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 4) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 4-byte aligned");
-        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)a->n_planes * 4, stream) != hipSuccess)
+        if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 128) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 128-byte aligned");
+        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)sq_fuse_scratch_bytes(a->n_planes), stream) != hipSuccess)
             return fail(SQ_ERR_HIP, "sq_fuse_planes: cannot clear the scratch");
-        hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
-                           (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
-        P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
+        if (flat == 1) {
+            // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
+            hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
+                               (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+            P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
+        }
+        // the queues count in 32 bits
+        if (a->mode == SQ_FUSE_OVERWRITE && (int64_t)a->n_planes * h.n_items < (int64_t(1) << 31) && !getenv("SQ_FUSE_STATIC"))
+            P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + (((int64_t)a->n_planes * 4 + 127) & ~int64_t(127)));
     }
     const bool u16 = a->tile_dtype == SQ_U16;
 
@@ -829,14 +934,20 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (a->canvas_dtype != a->tile_dtype)
             return fail(SQ_ERR_INVALID, "sq_fuse_planes: overwrite mode keeps the tile dtype (canvas %d, tile %d)",
                         a->canvas_dtype, a->tile_dtype);
+#define SQ_OVERWRITE(T, F)                                                                                  \
+    do {                                                                                                      \
+        if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream);     \
+        return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream);                 \
+    } while (0)
         if (u16) {
-            if (flat == 0) return launch(fuse_overwrite_kernel<uint16_t, 0>, P, h.n_items, a->n_planes, stream);
-            if (flat == 1) return launch(fuse_overwrite_kernel<uint16_t, 1>, P, h.n_items, a->n_planes, stream);
-            return launch(fuse_overwrite_kernel<uint16_t, 2>, P, h.n_items, a->n_planes, stream);
+            if (flat == 0) SQ_OVERWRITE(uint16_t, 0);
+            if (flat == 1) SQ_OVERWRITE(uint16_t, 1);
+            SQ_OVERWRITE(uint16_t, 2);
         }
-        if (flat == 0) return launch(fuse_overwrite_kernel<uint8_t, 0>, P, h.n_items, a->n_planes, stream);
-        if (flat == 1) return launch(fuse_overwrite_kernel<uint8_t, 1>, P, h.n_items, a->n_planes, stream);
-        return launch(fuse_overwrite_kernel<uint8_t, 2>, P, h.n_items, a->n_planes, stream);
+        if (flat == 0) SQ_OVERWRITE(uint8_t, 0);
+        if (flat == 1) SQ_OVERWRITE(uint8_t, 1);
+        SQ_OVERWRITE(uint8_t, 2);
+#undef SQ_OVERWRITE
     }
     // feather
     const bool f32out = a->canvas_dtype == SQ_F32;

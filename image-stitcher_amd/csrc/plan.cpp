@@ -373,6 +373,10 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             tail_at[x] = tail;
             tail += lane_len[x] - common;
         }
+        if (order_mode == 2) {   // the header is already in the table: patch the field
+            hd.lane_items = common;
+            std::memcpy(plan->table.ptr, &hd, sizeof hd);
+        }
         std::vector<int64_t> seen(nblk, 0);
         for_each_item([&](const Item &it) {
             const int k = key_of(it);

@@ -275,8 +275,8 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
         fp = pointer_table(flats, canvas.device)
         keep.append(fp)
         a.flat_ptrs_dev = fp.data_ptr()
-        nbytes = L.sq_fuse_scratch_bytes(n_planes)
-        scratch = torch.empty(max(16, int(nbytes)), dtype=torch.uint8, device=canvas.device)
+    if n_planes > 0:   # gain classes + work-queue counters (torch allocations are 512-byte aligned)
+        scratch = torch.empty(int(L.sq_fuse_scratch_bytes(n_planes)), dtype=torch.uint8, device=canvas.device)
         keep.append(scratch)
         a.scratch_dev = scratch.data_ptr()
         a.scratch_bytes = scratch.numel()

@@ -112,8 +112,9 @@ typedef struct sq_fuse_args {
     int32_t canvas_dtype; /* overwrite: == tile_dtype; feather: tile_dtype or SQ_F32       */
     int32_t n_planes;
     int32_t mode; /* must match the plan                                               */
-    /* optional scratch, sq_fuse_scratch_bytes(n_planes) bytes: lets the call classify each plane's   */
-    /* float32 gains (all normal floats?) and use the shortened exact divide; NULL = generic divide   */
+    /* optional scratch, sq_fuse_scratch_bytes(n_planes) bytes, 128-byte aligned: lets the call classify */
+    /* each plane's float32 gains (all normal floats? -> shortened exact divide) and hand out work      */
+    /* through per-XCD device queues; NULL = generic divide, static work split                          */
     void *scratch_dev;
     int64_t scratch_bytes;
 } sq_fuse_args;
