@@ -78,7 +78,10 @@ struct FuseParams {
     int32_t n_planes;
 };
 constexpr int QUEUE_STRIDE = 32;   // uint32 words between the counters
-constexpr int QUEUE_CHUNK = 8;     // consecutive lane positions a workgroup takes per atomic
+#ifndef SQ_QUEUE_CHUNK
+#define SQ_QUEUE_CHUNK 8
+#endif
+constexpr int QUEUE_CHUNK = SQ_QUEUE_CHUNK;   // consecutive lane positions a workgroup takes per atomic
 
 template <typename T>
 __device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int tile) {

@@ -278,13 +278,15 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 
     // ---- work items, generated straight into their final place in the table -----------------------
     // Order (overwrite mode): "one tile-row block per XCD".  Items are grouped by the block of
-    // BLOCK_ROWS tile rows they read (all tiles, in tile order; a stable counting sort).  Workgroup b
-    // of the persistent grid takes items b, b + G, ... and workgroups are dealt to the 8 XCDs
-    // round-robin, so list position i is served by XCD i % 8 (observed placement: a speed matter
-    // only).  Row block r is therefore laid out on positions == r (mod 8): the ~128 workgroups
-    // resident on one XCD all read the same 8 rows of the flatfield at the same time, which are
-    // fetched into that XCD's L2 once instead of once per tile.  Every item still moves whole row
-    // segments, so HBM sees the same contiguous runs, in a different order.  Zero-fill items go last.
+    // BLOCK_ROWS tile rows they read (all tiles, in tile order; a stable counting sort), and row block r
+    // is laid out on list positions == r (mod 8): lane r mod 8.  The fusion kernel's workgroups pull
+    // chunks of consecutive positions of the lane of the XCD they run on (fuse.hip; with the static
+    // fallback, workgroup b takes b, b + G, ... and workgroups are dealt to the XCDs round-robin, which
+    // comes to the same lanes), so the workgroups resident on one XCD all read the same few rows of the
+    // flatfield at the same time, fetched into that XCD's L2 once instead of once per tile.  Positions
+    // [0, 8 * lane_items) are interleaved this way (header field); the lanes' leftovers and the zero-fill
+    // items follow.  Every item still moves whole row segments, so HBM sees the same contiguous runs, in
+    // a different order.
     //   SQ_PLAN_ORDER=0 keeps span order, 1 = row blocks without the XCD interleave (experiments).
     const char *order_env = getenv("SQ_PLAN_ORDER");
     const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : 0;
