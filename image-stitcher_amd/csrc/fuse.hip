@@ -76,12 +76,13 @@ struct FuseParams {
     uint32_t *queue;              // 9 chunk counters (8 XCD lanes + the rest), one 128-byte line each; NULL = static stride
     int32_t lane_items;           // list positions [0, 8 * lane_items) of a plane are lane-interleaved
     int32_t n_planes;
+    int32_t chunk;                // consecutive lane positions a workgroup takes per atomic, 1..QUEUE_CHUNK
 };
 constexpr int QUEUE_STRIDE = 32;   // uint32 words between the counters
 #ifndef SQ_QUEUE_CHUNK
 #define SQ_QUEUE_CHUNK 8
 #endif
-constexpr int QUEUE_CHUNK = SQ_QUEUE_CHUNK;   // consecutive lane positions a workgroup takes per atomic
+constexpr int QUEUE_CHUNK = SQ_QUEUE_CHUNK;   // most consecutive lane positions a workgroup takes per atomic
 
 template <typename T>
 __device__ __forceinline__ const T *tile_ptr(const FuseParams &P, int plane, int tile) {
@@ -513,7 +514,7 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
     auto settle = [&](uint32_t c) -> Chunk {   // thread 0: make (given_up, c) a real chunk or move on
         while (true) {
             const int q = queue_of(given_up);
-            if ((uint64_t)c * QUEUE_CHUNK < total_of(q)) return {q, c};
+            if ((uint64_t)c * (uint32_t)P.chunk < total_of(q)) return {q, c};
             if (++given_up > 8) return {-1, 0u};
             c = atomicAdd(&P.queue[queue_of(given_up) * QUEUE_STRIDE], 1u);
         }
@@ -531,8 +532,8 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
         uint32_t pending = 0;
         const bool pull = threadIdx.x == 0 && given_up <= 8;
         if (pull) pending = atomicAdd(&P.queue[queue_of(given_up) * QUEUE_STRIDE], 1u);   // next chunk; looked at after this one
-        const uint32_t u0 = c * (uint32_t)QUEUE_CHUNK;
-        const int count = (int)min((uint32_t)QUEUE_CHUNK, total_of(q) - u0);
+        const uint32_t u0 = c * (uint32_t)P.chunk;
+        const int count = (int)min((uint32_t)P.chunk, total_of(q) - u0);
         if ((int)threadIdx.x < count) {   // one descriptor per thread: queue position -> (plane, list position)
             const uint32_t per_plane = per_plane_of(q);
             const uint32_t u = u0 + threadIdx.x;
@@ -785,7 +786,11 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
     }
     const int grid_override = getenv("SQ_FUSE_GRID") ? atoi(getenv("SQ_FUSE_GRID")) : 0;
     const int64_t blocks = std::min<int64_t>(n_work, grid_override > 0 ? grid_override : it->second);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, stream, P, n_items, n_work);
+    // work-queue chunk: QUEUE_CHUNK items per atomic when every workgroup gets many chunks, fewer for small
+    // launches so that the last round does not leave workgroups idle
+    FuseParams Q = P;
+    Q.chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(QUEUE_CHUNK, n_work / (blocks * 16)));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Q, n_items, n_work);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_planes: launch failed: %s", hipGetErrorString(e));
     return SQ_OK;
@@ -927,8 +932,12 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
                                (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
             P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
         }
-        // the queues count in 32 bits
-        if (a->mode == SQ_FUSE_OVERWRITE && (int64_t)a->n_planes * h.n_items < (int64_t(1) << 31) && !getenv("SQ_FUSE_STATIC"))
+        // the queues count in 32 bits; a launch with fewer than ~64 items per resident workgroup is over
+        // before the queues pay for their barriers (measured on the 8x8-grid, one-plane case): static walk
+        const int64_t n_work = (int64_t)a->n_planes * h.n_items;
+        // (SQ_FUSE_QUEUE=1 forces the queues whatever the size -- tests; SQ_FUSE_STATIC=1 the static walk)
+        if (a->mode == SQ_FUSE_OVERWRITE && (n_work >= 100000 || getenv("SQ_FUSE_QUEUE")) && n_work < (int64_t(1) << 31) &&
+            !getenv("SQ_FUSE_STATIC"))
             P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + (((int64_t)a->n_planes * 4 + 127) & ~int64_t(127)));
     }
     const bool u16 = a->tile_dtype == SQ_U16;

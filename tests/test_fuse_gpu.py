@@ -261,10 +261,13 @@ def test_fast_and_generic_divide_agree_on_real_planes(dtype):
     assert (~same).sum() <= n      # at most one voxel per tile differs (pixel (0, 0) where it is visible)
 
 
+@pytest.mark.parametrize('queues', [False, True])
 @pytest.mark.parametrize('seed', range(24))
-def test_fuzz_geometry_dtype_flat_mode(seed):
+def test_fuzz_geometry_dtype_flat_mode(seed, queues, monkeypatch):
     """Random tile sizes (down to a few pixels: rows shorter than one 16-byte vector), canvas pitches,
-    rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes."""
+    rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes; the overwrite
+    kernel with its static walk (what launches this small take) and with the per-XCD work queues forced."""
+    monkeypatch.setenv('SQ_FUSE_QUEUE' if queues else 'SQ_FUSE_STATIC', '1')
     rng = np.random.default_rng(1000 + seed)
     dtype = ['uint16', 'uint8'][seed % 2]
     th, tw = int(rng.integers(1, 70)), int(rng.integers(1, 300))
@@ -362,3 +365,22 @@ def test_padded_tile_and_canvas_pitches_through_the_c_abi():
         assert (got[p][:, cw:] == 0xBEEF).all()                 # the pitch padding is never written
     a.canvas_pitch = cw - 1
     assert L.sq_fuse_planes(C.byref(a), native._stream_ptr()) == -1 and b'pitch' in L.sq_last_error()
+
+
+@pytest.mark.parametrize('planes', [1, 3])
+def test_work_queues_on_a_registered_grid(planes, monkeypatch):
+    """The per-XCD queues on a lane-interleaved plan (registered 5x6 grid, cropped tiles, float32 gains, several
+    planes): chunks that straddle planes, lanes of unequal length, the rest queue and stealing all occur."""
+    monkeypatch.setenv('SQ_FUSE_QUEUE', '1')
+    from image_stitcher_amd import placement
+    rng = np.random.default_rng(99)
+    th, tw = 72, 200
+    s = placement.Shifts((2, -31), (-19, -3))
+    rects = placement.grid_rects(5, 6, tw, th, s)          # (rows, cols, width, height)
+    wc, hc = placement.canvas_size(5, 6, tw, th, use_registration=True, shifts=s)
+    tiles = rng.integers(0, 65536, size=(planes, 30, th, tw)).astype(np.uint16)
+    flats = [(0.5 + rng.random((th, tw))).astype(np.float32) for _ in range(planes)]
+    got, plan = run_fuse(rects, tiles, hc, wc, flats_np=flats, n_planes=planes)
+    assert plan.n_items > 64
+    for p in range(planes):
+        np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(tiles[p]), rects, hc, wc, flats[p]))
