@@ -464,47 +464,17 @@ __device__ __forceinline__ const T *sgpr(const T *p) {
     return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
 }
 
-template <typename T, int FLAT, bool DYN>
-__global__ __launch_bounds__(256, (FLAT == 1 ? (sizeof(T) == 2 ? SQ_WAVES_F32 : 1) : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
-void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-
-    if (!DYN) {
-        // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
-        // pointer are fetched while the current item streams
-        int64_t work = blockIdx.x;
-        if (work >= n_work) return;
-        int plane = (int)(work / n_items);
-        Item it = P.items[work - plane * n_items];
-        const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
-        while (true) {
-            const int64_t nwork = work + gridDim.x;
-            const bool more = nwork < n_work;
-            int nplane = plane;
-            Item nit = it;
-            const T *ntile = nullptr;
-            if (more) {
-                nplane = (int)(nwork / n_items);
-                nit = P.items[nwork - nplane * n_items];
-                ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
-            }
-            process_item<T, FLAT>(P, plane, it, tile, wave, lane);
-            if (!more) break;
-            work = nwork;
-            plane = nplane;
-            it = nit;
-            tile = ntile;
-        }
-        return;
-    }
-
-    // ---- dynamic: chunked per-XCD queues -------------------------------------------------------
+// The queue walk shared by the fusion kernels: calls body(plane, item, aux) for every (plane, item) this
+// workgroup is handed, all threads of the workgroup together, arguments in scalar registers.
+// aux = pre(plane, item) is evaluated by the thread that loads the descriptor (the overwrite kernel
+// fetches the tile pointer there, so that eight of them are in flight at once).
+template <typename Pre, typename Body>
+__device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const int64_t n_items, Pre pre, Body body) {
     __shared__ int s_q[2];
     __shared__ uint32_t s_c[2];
     __shared__ Item s_item[QUEUE_CHUNK];          // the chunk's descriptors, loaded by QUEUE_CHUNK threads at once
-    __shared__ const T *s_tile[QUEUE_CHUNK];
     __shared__ int s_plane[QUEUE_CHUNK];
+    __shared__ const void *s_aux[QUEUE_CHUNK];
     const int home = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // HW_REG_XCC_ID[3:0]
     // queue q holds n_planes * per_plane(q) positions; 32-bit arithmetic (the host checks the sizes)
     auto per_plane_of = [&](int q) { return (uint32_t)(q < 8 ? (int64_t)P.lane_items : n_items - 8 * (int64_t)P.lane_items); };
@@ -542,19 +512,58 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
             const Item it = P.items[q < 8 ? (int64_t)r * 8 + q : 8 * (int64_t)P.lane_items + r];
             s_item[threadIdx.x] = it;
             s_plane[threadIdx.x] = plane;
-            s_tile[threadIdx.x] = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+            s_aux[threadIdx.x] = pre(plane, it);
         }
         __syncthreads();
-        for (int j = 0; j < count; ++j) {
-            const Item it = sgpr(s_item[j]);
-            process_item<T, FLAT>(P, sgpr(s_plane[j]), it, sgpr(s_tile[j]), wave, lane);
-        }
+        for (int j = 0; j < count; ++j) body(sgpr(s_plane[j]), sgpr(s_item[j]), sgpr(s_aux[j]));
         if (threadIdx.x == 0) {
             const Chunk nxt = pull ? settle(pending) : Chunk{-1, 0u};
             s_q[(iter + 1) & 1] = nxt.q;
             s_c[(iter + 1) & 1] = nxt.c;
         }
     }
+}
+
+template <typename T, int FLAT, bool DYN>
+__global__ __launch_bounds__(256, (FLAT == 1 ? (sizeof(T) == 2 ? SQ_WAVES_F32 : 1) : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
+void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (!DYN) {
+        // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
+        // pointer are fetched while the current item streams
+        int64_t work = blockIdx.x;
+        if (work >= n_work) return;
+        int plane = (int)(work / n_items);
+        Item it = P.items[work - plane * n_items];
+        const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+        while (true) {
+            const int64_t nwork = work + gridDim.x;
+            const bool more = nwork < n_work;
+            int nplane = plane;
+            Item nit = it;
+            const T *ntile = nullptr;
+            if (more) {
+                nplane = (int)(nwork / n_items);
+                nit = P.items[nwork - nplane * n_items];
+                ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
+            }
+            process_item<T, FLAT>(P, plane, it, tile, wave, lane);
+            if (!more) break;
+            work = nwork;
+            plane = nplane;
+            it = nit;
+            tile = ntile;
+        }
+        return;
+    }
+    for_each_queued_item(
+        P, n_items,
+        [&](int plane, const Item &it) -> const void * { return it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr; },
+        [&](int plane, const Item &it, const void *tile) {
+            process_item<T, FLAT>(P, plane, it, static_cast<const T *>(tile), wave, lane);
+        });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -733,15 +742,12 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
 #ifndef SQ_WAVES_FEATHER_F32
 #define SQ_WAVES_FEATHER_F32 5
 #endif
-template <typename T, typename OutT, int FLAT>
+template <typename T, typename OutT, int FLAT, bool DYN>
 __global__ __launch_bounds__(256, (FLAT == 1 && sizeof(T) == 2 && sizeof(OutT) == 2 ? SQ_WAVES_FEATHER_F32 : 1))
-void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
-                                                            const int64_t n_work) {
+void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
-        const int plane = (int)(work / n_items);
-        const Item it = P.items[work - plane * n_items];
+    auto one_item = [&](int plane, const Item &it, const void * = nullptr) {
         const int nref = it.nref;
         if (sizeof(OutT) == sizeof(T) && FLAT != 2 && nref <= 1) {
             // nothing to blend: uncovered canvas, or one tile -> the overwrite kernel's pipelined copy
@@ -757,13 +763,23 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items,
                 one.c = rf.src_x + it.c;
             }
             process_item<T, FLAT == 2 ? 0 : FLAT, 1>(P, plane, one, tile, wave, lane);
-            continue;
+            return;
         }
         // float32 gains the pre-pass found all normal: the 8-slot divide, bit-identical to the IEEE
         // quotient for this operand class (exhaustive self-test), instead of the 11-slot generic one
         const bool fast = FLAT == 1 && P.flat_class && P.flat_class[plane] == 0;
         if (fast) blend_item<T, OutT, FLAT, true>(P, plane, it, threadIdx.x);
         else blend_item<T, OutT, FLAT, false>(P, plane, it, threadIdx.x);
+    };
+    if (DYN) {
+        // single-tile and blended items cost very differently: the queues (one "rest" queue here, the
+        // feather plan is not lane-interleaved) keep every workgroup busy until the end
+        for_each_queued_item(P, n_items, [](int, const Item &) -> const void * { return nullptr; }, one_item);
+    } else {
+        for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+            const int plane = (int)(work / n_items);
+            one_item(plane, P.items[work - plane * n_items]);
+        }
     }
 }
 
@@ -936,8 +952,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         // before the queues pay for their barriers (measured on the 8x8-grid, one-plane case): static walk
         const int64_t n_work = (int64_t)a->n_planes * h.n_items;
         // (SQ_FUSE_QUEUE=1 forces the queues whatever the size -- tests; SQ_FUSE_STATIC=1 the static walk)
-        if (a->mode == SQ_FUSE_OVERWRITE && (n_work >= 100000 || getenv("SQ_FUSE_QUEUE")) && n_work < (int64_t(1) << 31) &&
-            !getenv("SQ_FUSE_STATIC"))
+        if ((n_work >= 100000 || getenv("SQ_FUSE_QUEUE")) && n_work < (int64_t(1) << 31) && !getenv("SQ_FUSE_STATIC"))
             P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + (((int64_t)a->n_planes * 4 + 127) & ~int64_t(127)));
     }
     const bool u16 = a->tile_dtype == SQ_U16;
@@ -965,11 +980,16 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     const bool f32out = a->canvas_dtype == SQ_F32;
     if (!f32out && a->canvas_dtype != a->tile_dtype)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: feather canvas must be float32 or the tile dtype");
-#define SQ_FEATHER(T, O)                                                                             \
-    do {                                                                                             \
-        if (flat == 0) return launch(fuse_feather_kernel<T, O, 0>, P, h.n_items, a->n_planes, stream); \
-        if (flat == 1) return launch(fuse_feather_kernel<T, O, 1>, P, h.n_items, a->n_planes, stream); \
-        return launch(fuse_feather_kernel<T, O, 2>, P, h.n_items, a->n_planes, stream);               \
+#define SQ_FEATHER_F(T, O, F)                                                                              \
+    do {                                                                                                    \
+        if (P.queue) return launch(fuse_feather_kernel<T, O, F, true>, P, h.n_items, a->n_planes, stream);  \
+        return launch(fuse_feather_kernel<T, O, F, false>, P, h.n_items, a->n_planes, stream);              \
+    } while (0)
+#define SQ_FEATHER(T, O)                 \
+    do {                                 \
+        if (flat == 0) SQ_FEATHER_F(T, O, 0); \
+        if (flat == 1) SQ_FEATHER_F(T, O, 1); \
+        SQ_FEATHER_F(T, O, 2);           \
     } while (0)
     if (u16) {
         if (f32out) SQ_FEATHER(uint16_t, float);
@@ -978,4 +998,5 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (f32out) SQ_FEATHER(uint8_t, float);
     SQ_FEATHER(uint8_t, uint8_t);
 #undef SQ_FEATHER
+#undef SQ_FEATHER_F
 }

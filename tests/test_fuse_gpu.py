@@ -265,8 +265,8 @@ def test_fast_and_generic_divide_agree_on_real_planes(dtype):
 @pytest.mark.parametrize('seed', range(24))
 def test_fuzz_geometry_dtype_flat_mode(seed, queues, monkeypatch):
     """Random tile sizes (down to a few pixels: rows shorter than one 16-byte vector), canvas pitches,
-    rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes; the overwrite
-    kernel with its static walk (what launches this small take) and with the per-XCD work queues forced."""
+    rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes; the kernels
+    with their static walk (what launches this small take) and with the device work queues forced."""
     monkeypatch.setenv('SQ_FUSE_QUEUE' if queues else 'SQ_FUSE_STATIC', '1')
     rng = np.random.default_rng(1000 + seed)
     dtype = ['uint16', 'uint8'][seed % 2]
