@@ -40,3 +40,20 @@ run('crop 122, 3-px gaps between tiles (thin zero spans)', 122, 122, T - 244 + 3
 run('full tiles, abutting, canvas width +5 (odd pitch)', 0, 0, T, T, pad_w=5)
 run('crop 128 horizontally only', 128, 0, T - 256, T)
 run('crop 128 vertically only', 0, 128, T, T - 256)
+
+
+def run_src(name, src_x, w=1792):
+    """Destination seams on line boundaries (w = 1792 px = 28 lines, pitch a multiple of 64 px); only the
+    SOURCE phase varies: how much do tile rows read at an odd byte phase cost?"""
+    rects = [(128, src_x, T - 256, w, r * (T - 256), c * w) for r in range(G) for c in range(G)]
+    wc, hc = G * w, G * (T - 256)
+    plan = native.FusePlan(np.array(rects), T, T, hc, wc)
+    canvas = torch.empty((P, hc, wc), dtype=torch.uint16, device=dev)
+    ms = min(timeit(lambda: native.fuse_planes(plan, tiles, canvas)) for _ in range(2))
+    alg = P * plan.covered_voxels * 4
+    print(f'{name:58s} src_x {src_x:4d}: {ms:7.3f} ms {alg/ms/1e6:7.1f} GB/s', flush=True)
+    del canvas
+
+
+for sx in (128, 129, 130, 132, 136, 144, 160, 192, 122):
+    run_src('aligned seams, source phase only', sx)
