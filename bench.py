@@ -119,6 +119,7 @@ def main():
         ffs = [torch.from_numpy(synth.synthetic_flatfield(TILE, TILE, np.float32) * np.float32(1 + 0.03125 * c)).to(dev)
                for c in range(C_eff)]
         flat_list = [ffs[p // Z_eff] for p in range(n_planes)]
+    flat_ptrs = native.pointer_table(flat_list, dev) if flat_list else None
     canvas = torch.empty((n_planes, hc, wc), dtype=torch.uint16, device=dev)
     xs = [spec.stage_mm(0, c)[0] for c in range(g)]
     ys = [spec.stage_mm(r, 0)[1] for r in range(g)]
@@ -145,13 +146,22 @@ def main():
         lap[name] = lap.get(name, 0.0) + (t - t_prev)
         return t
 
-    def step(record):
+    serial = bool(os.environ.get('SQ_BENCH_SERIAL'))
+
+    def start_registration():
+        # registration: centre pairs on the registration plane (stitcher.py:422-498), enqueued only
+        return registration.register_grid_center_async(reg_plane, g, g, xs, ys, spec.pixel_size_um,
+                                                       spec.pixel_binning, normalization='phase')
+
+    def step(record, pending, more):
+        """One region: collect its registration, all-gather, geometry + span plan, one fusion launch.  Regions
+        are independent, so the NEXT region's registration is enqueued ahead of this region's fusion launch:
+        its kernels run first, and its read-back, planning and launch happen while this fusion runs (the
+        device never waits for the host's millisecond of planning).  SQ_BENCH_SERIAL=1 keeps the steps apart."""
         if os.environ.get('SQ_BENCH_BREAKDOWN') == '2':
             torch.cuda.synchronize()      # diagnostic only: lets the host timings below exclude GPU back-pressure
         t = time.perf_counter()
-        # registration: centre pairs on the registration plane (stitcher.py:422-498)
-        shifts = registration.register_grid_center(reg_plane, g, g, xs, ys, spec.pixel_size_um,
-                                                   spec.pixel_binning, normalization='phase')
+        shifts = (pending or start_registration()).result()
         t = tick('register', t)
         # the shift table is all-gathered (RCCL) beside the fusion launch: a rank fuses with its own
         # region's shifts, the other rows are only needed when the table is written out
@@ -167,15 +177,23 @@ def main():
         t = tick('rects', t)
         plan = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE)
         t = tick('plan', t)
+        nxt = start_registration() if (more and not serial) else None
+        t = tick('register_next', t)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        native.fuse_planes(plan, None, canvas, flat_list, tile_ptrs=ptrs)
+        native.fuse_planes(plan, None, canvas, flat_list, tile_ptrs=ptrs, flat_ptrs=flat_ptrs)
         if record:
             e1.record()
             fuse_events.append((e0, e1))
         state['plan'], state['shifts'] = plan, mine
         tick('fuse_launch', t)
+        return nxt
+
+    def run_steps(n, record):
+        pending = None
+        for k in range(n):
+            pending = step(record, pending, k + 1 < n)
 
     def finish_gathers():
         # inside the timed region: every step's table has arrived and holds this rank's row
@@ -191,12 +209,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(args.warmup, False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)      # K registrations, K plans, K fusion launches, all inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -236,7 +252,8 @@ def main():
                    'canvas': [hc, wc], 'tiles_per_plane': g * g,
                    'parallelism': f'one region per GPU x{world}, shift-table all-gather' if world > 1 else 'single GPU',
                    'shifts': {'h': list(state['shifts'].h_shift), 'v': list(state['shifts'].v_shift)},
-                   'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes'},
+                   'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes; the next '
+                           "region's registration is enqueued ahead of the fusion launch (regions are independent)"},
         'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_kernel<u16,f32 flat>' if wl['flat'] else 'fuse_overwrite_kernel<u16>',
                      'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,

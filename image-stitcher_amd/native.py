@@ -195,8 +195,12 @@ class FusePlan:
         key = str(device)
         if key not in self._dev:
             dev = torch.empty(max(self.table_bytes, 1), dtype=torch.uint8, device=device)
+            # on the read-back / upload stream, not the caller's: the copy must not queue behind a fusion
+            # launch that is still running there (the entry point waits for the copy, so the table is
+            # complete before anything later is launched)
             with torch.cuda.device(dev.device):
-                _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr()), 'sq_fuse_plan_upload')
+                side = _copy_stream(dev.device)
+                _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr(side)), 'sq_fuse_plan_upload')
             self._dev[key] = dev
         return self._dev[key]
 
@@ -212,20 +216,35 @@ class FusePlan:
             pass
 
 
+def upload_small(host, device):
+    """A small host tensor -> device, copied on the read-back / upload stream instead of the caller's: a
+    pageable host-to-device copy blocks the host until everything queued before it on ITS stream is done,
+    and on the caller's stream that can be a 35 ms fusion launch.  Returns when the data is on the device."""
+    import torch
+    device = torch.device(device)
+    dst = torch.empty(host.shape, dtype=host.dtype, device=device)
+    if dst.numel():
+        with torch.cuda.stream(_copy_stream(device)):
+            dst.copy_(host)
+    return dst
+
+
 def pointer_table(tensors: Sequence, device):
     """Device int64 tensor of data_ptr()s (0 for None); the caller keeps ``tensors`` alive."""
     import torch
     ptrs = [0 if t is None else int(t.data_ptr()) for t in tensors]
-    return torch.tensor(ptrs, dtype=torch.int64).to(device)
+    return upload_small(torch.tensor(ptrs, dtype=torch.int64), device)
 
 
-def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, stream=None) -> None:
+def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, stream=None, flat_ptrs=None) -> None:
     """Fuse all planes of ``canvas`` ([P, Hc, Wc] or [..., Hc, Wc] contiguous) from ``tiles``.
 
     tiles:     contiguous device tensor [P, N, H, W] (N = plan.n_tiles), or None with
                ``tile_ptrs`` = device int64 tensor [P*N] of tile pointers (dense H x W tiles).
     flats:     None, or a list of P device tensors / None (H x W float32 or float64 gains);
                all non-None entries must share one dtype.
+    flat_ptrs: optionally ``pointer_table(flats, device)`` made earlier, for callers that fuse with the same
+               gains again and again (saves a small blocking upload per call).
     """
     import torch
     L = lib()
@@ -272,7 +291,9 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
             if f is not None and (tuple(f.shape) != (plan.tile_h, plan.tile_w) or not f.is_contiguous()):
                 raise ValueError("flatfield must be a contiguous tile_h x tile_w tensor")
         a.flat_dtype = sq_dtype_of(np_dtype_of_torch(dts.pop()))
-        fp = pointer_table(flats, canvas.device)
+        fp = flat_ptrs if flat_ptrs is not None else pointer_table(flats, canvas.device)
+        if fp.dtype != torch.int64 or fp.numel() != n_planes:
+            raise ValueError("flat_ptrs must be int64 with one entry per plane")
         keep.append(fp)
         a.flat_ptrs_dev = fp.data_ptr()
     if n_planes > 0:   # gain classes + work-queue counters (torch allocations are 512-byte aligned)
@@ -351,16 +372,39 @@ def downsample2(planes, out=None, stream=None):
     return out
 
 
-class PendingRegistration:
-    """Results of an enqueued sq_register_pairs; ``fetch()`` synchronises and returns them."""
+_COPY_STREAMS = {}
 
-    def __init__(self, res_dev, keep, n):
-        self._res, self._keep, self._n = res_dev, keep, n
+
+def _copy_stream(device):
+    """One stream per device for small result read-backs, so that they do not queue behind whatever the
+    caller has enqueued on its own stream since (e.g. a 35 ms fusion launch)."""
+    import torch
+    key = (device.type, device.index)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COPY_STREAMS[key]
+
+
+class PendingRegistration:
+    """Results of an enqueued sq_register_pairs; ``fetch()`` waits for THAT batch (not for later work on
+    the caller's stream) and returns them."""
+
+    def __init__(self, res_dev, keep, n, done=None):
+        self._res, self._keep, self._n, self._done = res_dev, keep, n, done
 
     def fetch(self) -> np.ndarray:
+        import torch
         if self._n == 0:
             return np.zeros(0, dtype=RESULT_DTYPE)
-        out = self._res.cpu().numpy().view(RESULT_DTYPE).copy()
+        if self._done is not None:
+            side = _copy_stream(self._res.device)
+            side.wait_event(self._done)
+            self._res.record_stream(side)
+            with torch.cuda.stream(side):
+                host = self._res.cpu()
+        else:
+            host = self._res.cpu()
+        out = host.numpy().view(RESULT_DTYPE).copy()
         self._keep = None
         return out
 
@@ -390,7 +434,7 @@ def register_pairs_async(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, ups
             or (pairs['mov_x0'] + n1 > w).any()):
         raise ValueError("crop reaches outside its tile")
     ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=device)
-    pairs_dev = torch.from_numpy(pairs.view(np.uint8).reshape(-1)).to(device)
+    pairs_dev = upload_small(torch.from_numpy(pairs.view(np.uint8).reshape(-1)), device)
     res_dev = torch.zeros(npairs * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
     a = _RegisterArgs()
     a.tile_ptrs_dev = ptrs
@@ -408,7 +452,9 @@ def register_pairs_async(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, ups
     a.workspace_dev = ws.data_ptr()
     a.workspace_bytes = ws.numel()
     _check(L.sq_register_pairs(C.byref(a), _stream_ptr(stream)), 'sq_register_pairs')
-    return PendingRegistration(res_dev, (ws, pairs_dev, minmax, tiles, tile_ptrs), npairs)
+    done = torch.cuda.Event()
+    done.record(stream if stream is not None else torch.cuda.current_stream())
+    return PendingRegistration(res_dev, (ws, pairs_dev, minmax, tiles, tile_ptrs), npairs, done)
 
 
 def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_factor: int = 10,

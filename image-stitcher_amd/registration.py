@@ -108,10 +108,33 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+class PendingShifts:
+    """Centre-pair registration in flight on the device; ``result()`` synchronises and returns the Shifts."""
+
+    def __init__(self, finish):
+        self._finish, self._shifts = finish, None
+
+    def result(self) -> Shifts:
+        if self._finish is not None:
+            self._shifts = self._finish()
+            self._finish = None
+        return self._shifts
+
+
 def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], ys: Sequence[float],
                          pixel_size_um: float, pixel_binning: int, normalization='phase',
                          scan_pattern: str = 'Unidirectional', tile_index=None) -> Shifts:
-    """calculate_shifts (stitcher.py:422-498) on a device stack of one (channel, z) plane.
+    """calculate_shifts (stitcher.py:422-498) on a device stack of one (channel, z) plane (synchronises)."""
+    return register_grid_center_async(tiles, n_rows, n_cols, xs, ys, pixel_size_um, pixel_binning, normalization,
+                                      scan_pattern, tile_index).result()
+
+
+def register_grid_center_async(tiles, n_rows: int, n_cols: int, xs: Sequence[float], ys: Sequence[float],
+                               pixel_size_um: float, pixel_binning: int, normalization='phase',
+                               scan_pattern: str = 'Unidirectional', tile_index=None) -> PendingShifts:
+    """Enqueue calculate_shifts (stitcher.py:422-498) on a device stack of one (channel, z) plane and return
+    without synchronising: a caller with several independent regions enqueues the next region's
+    registration ahead of the current region's fusion and collects it while that fusion runs.
 
     ``tile_index(row, col) -> index into tiles`` (default row-major).  Picks the centre tile
     and its right / bottom neighbours; S-Pattern adds the pair one row below.  Only the tiles
@@ -130,7 +153,7 @@ def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], y
         vp.append((idx(ri, ci), idx(ri + 1, ci)))
     used = sorted({t for p in hp + vp for t in p})
     if not used:
-        return out
+        return PendingShifts(lambda: out)
     local = {t: i for i, t in enumerate(used)}
     ptrs = native.pointer_table([tiles[t] for t in used], tiles.device)
     np_dtype = native.np_dtype_of_torch(tiles.dtype)
@@ -167,18 +190,21 @@ def register_grid_center(tiles, n_rows: int, n_cols: int, xs: Sequence[float], y
         hq = launch(hp, horizontal_pair)
     elif vp:
         vq = launch(vp, vertical_pair)
-    if hq:
-        s = shifts_from_results(hq[0].fetch(), 10)[0]
-        out.h_shift = horizontal_shift_from(s[0], hq[2])
-        if len(hp) > 1:
-            out.h_shift_rev = horizontal_shift_from(s[1], hq[2])
-            out.h_shift_rev_odd = int(ri % 2 == 0)
-    if scan_pattern == 'S-Pattern' and out.h_shift_rev is None:
-        out.h_shift_rev = (0, 0)
-    if vq:
-        s = shifts_from_results(vq[0].fetch(), 10)[0]
-        out.v_shift = vertical_shift_from(s[0], vq[1])
-    return out
+    def finish() -> Shifts:
+        if hq:
+            s = shifts_from_results(hq[0].fetch(), 10)[0]
+            out.h_shift = horizontal_shift_from(s[0], hq[2])
+            if len(hp) > 1:
+                out.h_shift_rev = horizontal_shift_from(s[1], hq[2])
+                out.h_shift_rev_odd = int(ri % 2 == 0)
+        if scan_pattern == 'S-Pattern' and out.h_shift_rev is None:
+            out.h_shift_rev = (0, 0)
+        if vq:
+            s = shifts_from_results(vq[0].fetch(), 10)[0]
+            out.v_shift = vertical_shift_from(s[0], vq[1])
+        return out
+
+    return PendingShifts(finish)
 
 
 def all_pairs(n_rows: int, n_cols: int, height: int, width: int, max_x_overlap: int, max_y_overlap: int,
