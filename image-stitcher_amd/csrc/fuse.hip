@@ -54,7 +54,22 @@ template <typename S>
 __device__ __forceinline__ S ldg_s(const void *p) {
     return *(const SQ_GLOBAL S *)p;
 }
-__device__ __forceinline__ void stg_nt(void *p, u32x4 v) { __builtin_nontemporal_store(v, (SQ_GLOBAL u32x4 *)p); }
+#ifndef SQ_STORE_POLICY
+#define SQ_STORE_POLICY 0
+#endif
+__device__ __forceinline__ void stg_nt(void *p, u32x4 v) {
+#if SQ_STORE_POLICY == 0
+    __builtin_nontemporal_store(v, (SQ_GLOBAL u32x4 *)p);
+#elif SQ_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+#elif SQ_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif SQ_STORE_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    *(SQ_GLOBAL u32x4 *)p = v;
+#endif
+}
 template <typename S>
 __device__ __forceinline__ void stg_s(void *p, S v) {
     *(SQ_GLOBAL S *)p = v;
