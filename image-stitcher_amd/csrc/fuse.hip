@@ -193,6 +193,29 @@ __device__ __forceinline__ uint32_t flat_f32_fast_pair(uint32_t word, float g_lo
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
 
+// float64 gains: the compiler's IEEE sequence is v_div_scale x2, v_rcp_f64, two Newton steps, quotient,
+// residual, v_div_fmas, v_div_fixup.  For a numerator in [0, 65535] and a gain with 2^-100 <= |g| < 2^100
+// the scaling is the identity and the fix-up never fires, so the same arithmetic without those three
+// instructions yields the same double, bit for bit (sq_selftest_flat_divide_f64 compares the doubles and
+// the clipped integers for 2^15 random gains per binade x every numerator; tests/test_fuse_gpu.py).
+// v_cvt_u32_f64 saturates like its float32 sibling: clip + truncate in one instruction.
+__device__ __forceinline__ double div_u16_normal_f64(double n, double g) {
+    double r = __builtin_amdgcn_rcp(g);
+    r = fma(r, fma(-g, r, 1.0), r);
+    r = fma(r, fma(-g, r, 1.0), r);
+    const double q = n * r;
+    return fma(fma(-g, q, n), r, q);
+}
+__device__ __forceinline__ uint32_t cvt_u32_sat(double f) {
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ T flat_f64_fast(T v, double g) {
+    return (T)min(cvt_u32_sat(div_u16_normal_f64((double)v, g)), sizeof(T) == 1 ? 255u : 65535u);
+}
+
 template <typename T>
 __device__ __forceinline__ T flat_f64(T v, double g) {
     double q = __ddiv_rn((double)v, g);
@@ -340,14 +363,15 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
             for (int q = 0; q < VEC / 2; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    Pix<T>::set(px, 2 * q + e, flat_f64<T>(Pix<T>::get(px, 2 * q + e), S.g64[q][e]));
+                    Pix<T>::set(px, 2 * q + e, FAST ? flat_f64_fast<T>(Pix<T>::get(px, 2 * q + e), S.g64[q][e])
+                                                    : flat_f64<T>(Pix<T>::get(px, 2 * q + e), S.g64[q][e]));
         }
         stg_nt(J.drow + (v * VEC - J.mis), px);
     }
     if (k == 0 && J.edge_p >= 0) {
         T t = S.edge;
         if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T, RND>(t, S.eg32) : flat_f32<T, RND>(t, S.eg32);
-        if (FLAT == 2 && J.frow) t = flat_f64<T>(t, S.eg64);
+        if (FLAT == 2 && J.frow) t = FAST ? flat_f64_fast<T>(t, S.eg64) : flat_f64<T>(t, S.eg64);
         stg_s<T>(J.drow + J.edge_p, t);
     }
 }
@@ -425,7 +449,7 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
         return;
     }
     const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
-    const bool fast = FLAT == 1 && P.flat_class && P.flat_class[plane] == 0;
+    const bool fast = FLAT != 0 && P.flat_class && P.flat_class[plane] == 0;
     for (int rb = wave; rb < rows; rb += 4 * RB) {
         Row<T> J[RB];
 #pragma unroll
@@ -828,15 +852,18 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
 }
 
 // pre-pass: does a plane's flatfield hold anything outside the fast divide's range?
+template <typename G>
 __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *flat_ptrs, int64_t n, uint32_t *cls) {
     const int plane = blockIdx.y;
-    const float *f = static_cast<const float *>(flat_ptrs[plane]);
+    const G *f = static_cast<const G *>(flat_ptrs[plane]);
     if (!f) return;
+    const G lo = (G)__builtin_ldexp(1.0, FAST_MIN_EXP), hi = (G)__builtin_ldexp(1.0, FAST_END_EXP);
     bool odd = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     {
-        const float g = fabsf(ldg_s<float>(f + i));
-        odd |= !(g >= __builtin_ldexpf(1.0f, FAST_MIN_EXP) && g < __builtin_ldexpf(1.0f, FAST_END_EXP));   // NaN fails both
+        const G g = ldg_s<G>(f + i);
+        const G a = g < 0 ? -g : g;
+        odd |= !(a >= lo && a < hi);   // NaN fails both
     }
     if (__builtin_amdgcn_ballot_w64(odd) && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], 1u);
 }
@@ -890,6 +917,49 @@ extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int3
         e = hipGetLastError();
     }
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_flat_divide: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+// the float64 divide against the compiler's IEEE division: 2^15 pseudo-random gains per binade (all 52
+// mantissa bits from a counter hash) x every uint16 numerator; the doubles and the clipped integers
+__global__ __launch_bounds__(256) void selftest_divide_f64_kernel(int exponent0, int negative, uint64_t seed, unsigned long long *bad) {
+    const uint64_t id = ((uint64_t)blockIdx.y << 32) | (blockIdx.x * 256u + threadIdx.x);
+    uint64_t x = seed + id * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    const int exponent = exponent0 + (int)blockIdx.y;
+    // a few structured mantissas first: all zeros, all ones, single bits -- then the hash
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint64_t mant = x & ((1ull << 52) - 1);
+    if (t == 0) mant = 0;
+    else if (t == 1) mant = (1ull << 52) - 1;
+    else if (t < 54) mant = 1ull << (t - 2);
+    else if (t < 106) mant = ((1ull << 52) - 1) ^ (1ull << (t - 54));
+    const uint64_t bits = ((uint64_t)(exponent + 1023) << 52) | mant | (negative ? 0x8000000000000000ull : 0ull);
+    const double g = __longlong_as_double((long long)bits);
+    unsigned long long local = 0;
+    for (int v = 0; v < 65536; ++v) {
+        const double want = __ddiv_rn((double)v, g);
+        const double got = div_u16_normal_f64((double)v, g);
+        local += __double_as_longlong(want) != __double_as_longlong(got) && !(want == 0.0 && got == 0.0);
+        local += flat_f64<uint16_t>((uint16_t)v, g) != flat_f64_fast<uint16_t>((uint16_t)v, g);
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
+}
+
+extern "C" int sq_selftest_flat_divide_f64(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t seed,
+                                           uint64_t *mismatches_dev, void *stream) {
+    if (!mismatches_dev || exponent < FAST_MIN_EXP || n_binades < 1 || exponent + n_binades > FAST_END_EXP)
+        return fail(SQ_ERR_INVALID, "sq_selftest_flat_divide_f64: binades [%d, %d] outside the fast path's range [%d, %d]",
+                    exponent, exponent + n_binades - 1, FAST_MIN_EXP, FAST_END_EXP - 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_divide_f64_kernel, dim3(128, n_binades), dim3(256), 0, s, exponent, negative, seed,
+                           reinterpret_cast<unsigned long long *>(mismatches_dev));
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_flat_divide_f64: %s", hipGetErrorString(e));
     return SQ_OK;
 }
 
@@ -957,10 +1027,14 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 128) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 128-byte aligned");
         if (hipMemsetAsync(a->scratch_dev, 0, (size_t)sq_fuse_scratch_bytes(a->n_planes), stream) != hipSuccess)
             return fail(SQ_ERR_HIP, "sq_fuse_planes: cannot clear the scratch");
-        if (flat == 1) {
-            // classify every plane's gains once per call (reads H*W*4 B per plane, ~0.4 % of the launch)
-            hipLaunchKernelGGL(flat_classify_kernel, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
-                               (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+        if (flat) {
+            // classify every plane's gains once per call (reads H*W*4 (8) B per plane, ~0.4 % of the launch)
+            if (flat == 1)
+                hipLaunchKernelGGL(flat_classify_kernel<float>, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
+                                   (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+            else
+                hipLaunchKernelGGL(flat_classify_kernel<double>, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
+                                   (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
             P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
         }
         // the queues count in 32 bits; a launch with fewer than ~64 items per resident workgroup is over

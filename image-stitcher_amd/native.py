@@ -80,6 +80,7 @@ EXPORTS = {
     'sq_register_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    'sq_selftest_flat_divide_f64': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
     'sq_synth_tiles': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p]),
@@ -471,6 +472,15 @@ def selftest_flat_divide(exponent: int, n_binades: int, negative: bool, device) 
     out = torch.zeros(1, dtype=torch.int64, device=device)
     _check(lib().sq_selftest_flat_divide(int(exponent), int(n_binades), int(bool(negative)), out.data_ptr(),
                                          _stream_ptr()), 'sq_selftest_flat_divide')
+    return int(out.item())
+
+
+def selftest_flat_divide_f64(exponent: int, n_binades: int, negative: bool, seed: int, device) -> int:
+    """Mismatches between the shortened and the IEEE float64 flatfield divide on random gains (tests)."""
+    import torch
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(lib().sq_selftest_flat_divide_f64(int(exponent), int(n_binades), int(bool(negative)), int(seed) & (2 ** 64 - 1),
+                                             out.data_ptr(), _stream_ptr()), 'sq_selftest_flat_divide_f64')
     return int(out.item())
 
 

@@ -210,6 +210,12 @@ int sq_register_pairs(const sq_register_args *args, void *stream);
 int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
                             void *stream);
 
+/* The same for float64 gains (their shortened sequence = the compiler's IEEE division without its range
+ * handling): 2^15 pseudo-random gains per binade (from `seed`; all-zero, all-one and single-bit mantissas
+ * included) x all 65536 numerators; compares the quotient doubles and the clipped integers. */
+int sq_selftest_flat_divide_f64(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t seed,
+                                uint64_t *mismatches_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Synthetic tiles on the device (bench / tests only): the generator of
  * image-stitcher_amd/synth.py, bit for bit.  out_dev[i] is tile i (tile_h x tile_w, dense).

@@ -208,6 +208,20 @@ def test_flatfield_fast_and_slow_paths_mix_in_one_vector():
     np.testing.assert_array_equal(got[0], O.fuse_plane_overwrite(list(tiles[0]), rects, th, tw, flat))
 
 
+def test_fast_float64_divide_matches_ieee_on_random_gains():
+    """float64 gains: the shortened sequence (the compiler's IEEE division without its range handling) gives
+    the same double and the same clipped integer as the IEEE division, for 2^15 random gains per binade
+    (plus all-zero, all-one and single-bit mantissas) x every uint16 numerator, over all 200 binades."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    for k, e0 in enumerate(range(-100, 100, 50)):
+        assert native.selftest_flat_divide_f64(e0, 50, False, 1234 + k, dev) == 0, e0
+    for e0 in (-100, -1, 0, 16, 99):
+        assert native.selftest_flat_divide_f64(e0, 1, True, 99 + e0, dev) == 0, e0
+    with pytest.raises(native.NativeError, match='outside'):
+        native.selftest_flat_divide_f64(100, 1, False, 0, dev)
+
+
 def test_rects_clipped_by_the_canvas_and_empty_rects():
     """Rectangles that stick out of the canvas are clipped like the reference's python slices
     (stitcher.py:590-594); rectangles that start outside it or have no area write nothing."""
