@@ -179,8 +179,9 @@ def channel_file_token(channel: str) -> str:
     return channel.replace(' ', '_')
 
 
-def write_acquisition(spec: GridSpec, root: str) -> List[str]:
-    """Materialise ``spec`` as a Squid acquisition folder; returns the tile paths."""
+def write_acquisition(spec: GridSpec, root: str, ext: str = 'tiff') -> List[str]:
+    """Materialise ``spec`` as a Squid acquisition folder; returns the tile paths.  ``ext``: 'tiff' (own
+    writer) or 'bmp' / 'png' (uint8 tiles, through PIL) -- Squid saves .bmp or .tiff."""
     os.makedirs(root, exist_ok=True)
     with open(os.path.join(root, 'acquisition parameters.json'), 'w') as fh:
         json.dump(spec.acquisition_parameters(), fh, indent=2)
@@ -199,11 +200,17 @@ def write_acquisition(spec: GridSpec, root: str) -> List[str]:
                         for ci, ch in enumerate(spec.channels):
                             if (fov, z, ci, t) in set(map(tuple, spec.missing)):
                                 continue
-                            p = os.path.join(tdir, f'{region}_{fov}_{z}_{channel_file_token(ch)}.tiff')
+                            p = os.path.join(tdir, f'{region}_{fov}_{z}_{channel_file_token(ch)}.{ext}')
                             img = spec.tile(r, c, ri, t, z, ci)
                             if ch in spec.rgb_channels:   # three different planes of the same scene family
                                 img = np.stack([img, spec.tile(r, c, ri, t, z, ci + 17), spec.tile(r, c, ri, t, z, ci + 31)], axis=-1)
-                            write_tiff(p, img)
+                            if ext in ('tiff', 'tif'):
+                                write_tiff(p, img)
+                            else:
+                                from PIL import Image
+                                if img.dtype != np.uint8:
+                                    raise ValueError(f".{ext} tiles must be uint8")
+                                Image.fromarray(img).save(p)
                             paths.append(p)
         with open(os.path.join(tdir, 'coordinates.csv'), 'w') as fh:
             fh.write('\n'.join(lines) + '\n')

@@ -182,3 +182,23 @@ def test_run_writes_shift_table_single_process(tmp_path):
             t, region = key[1:].split('_', 1)
             store = os.path.join(st.output_folder, f'{t}_stitched', f'{region}_stitched.ome.zarr')
             np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
+
+
+@pytest.mark.parametrize('ext', ['bmp', 'png'])
+def test_bmp_and_png_tiles(tmp_path, ext):
+    """Squid also saves .bmp tiles (and the reference accepts .png): uint8 acquisition with registration,
+    decoded through PIL, against the oracle on the same files."""
+    from image_stitcher_amd.tiffio import read_image
+    from oracle import stitch_oracle as O
+    spec = synth.GridSpec(rows=2, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=17, dtype='uint8', noise=0, nz=2)
+    root = str(tmp_path / 'acq')
+    paths = synth.write_acquisition(spec, root, ext=ext)
+    assert all(p.endswith('.' + ext) for p in paths)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization='phase')
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    assert st.dtype == np.uint8 and st.num_z == 2
+    st.calculate_shifts(0, 'R0')
+    acq = O.parse_acquisition(root, read_image)
+    want_shifts = O.calculate_shifts(acq, 0, 'R0', read_image, '', 0, 'Unidirectional', 'phase')
+    assert (st.h_shift, st.v_shift) == (want_shifts['h_shift'], want_shifts['v_shift'])
+    np.testing.assert_array_equal(st.stitch_region(0, 'R0'), O.stitch_region(acq, 0, 'R0', read_image, True, want_shifts))
