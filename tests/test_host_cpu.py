@@ -249,3 +249,26 @@ def test_get_flatfields_standin_and_basicpy_delegation(tmp_path, monkeypatch):
     st.get_flatfields()
     assert calls == [dict(get_darkfield=False, smoothness_flatfield=1)] * 3
     assert all(float(st.flatfields[i][0, 0]) == 1.25 for i in range(3)) and float(st.flatfields[3][0, 0]) == 1.0
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 3), (3, 1), (1, 1)])
+def test_degenerate_grids_behave_like_the_reference(tmp_path, rows, cols):
+    """One row, one column or one tile: coordinate-only placement works; with -r the reference indexes
+    x_pos_list[1] / y_pos_list[1] (stitcher.py:444-445) and dies with IndexError -- so does the drop-in."""
+    from image_stitcher_amd.stitcher import Stitcher
+    from image_stitcher_amd.tiffio import read_image
+    from oracle import stitch_oracle as O
+    spec = synth.GridSpec(rows=rows, cols=cols, tile_h=64, tile_w=96, ov_y=16, ov_x=24, seed=21)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    acq = O.parse_acquisition(root, read_image)
+    want = O.stitch_region(acq, 0, 'R0', read_image, False, None)
+    st = Stitcher(StitchingParameters(input_folder=root))
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    assert st.calculate_output_dimensions(0, 'R0') == (want.shape[-1], want.shape[-2])
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True))
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    with pytest.raises(IndexError):
+        st.calculate_shifts(0, 'R0')
+    with pytest.raises(IndexError):
+        O.calculate_shifts(acq, 0, 'R0', read_image, '', 0, 'Unidirectional', 'phase')

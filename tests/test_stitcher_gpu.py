@@ -202,3 +202,17 @@ def test_bmp_and_png_tiles(tmp_path, ext):
     want_shifts = O.calculate_shifts(acq, 0, 'R0', read_image, '', 0, 'Unidirectional', 'phase')
     assert (st.h_shift, st.v_shift) == (want_shifts['h_shift'], want_shifts['v_shift'])
     np.testing.assert_array_equal(st.stitch_region(0, 'R0'), O.stitch_region(acq, 0, 'R0', read_image, True, want_shifts))
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 3), (3, 1), (1, 1)])
+def test_degenerate_grids_coordinate_mode(tmp_path, rows, cols):
+    """One row, one column, one tile (coordinate-only): fused canvas equals the oracle's."""
+    from image_stitcher_amd.tiffio import read_image
+    from oracle import stitch_oracle as O
+    spec = synth.GridSpec(rows=rows, cols=cols, tile_h=64, tile_w=96, ov_y=16, ov_x=24, seed=21, nz=2)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    st = Stitcher(StitchingParameters(input_folder=root))
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    acq = O.parse_acquisition(root, read_image)
+    np.testing.assert_array_equal(st.stitch_region(0, 'R0'), O.stitch_region(acq, 0, 'R0', read_image, False, None))
