@@ -290,9 +290,19 @@ def pyramid_vectors():
     print('[golden] pyramid vectors written')
 
 
+def degenerate_cases():
+    """One row, one column, one tile (coordinate-only; with -r the reference dies with IndexError at
+    stitcher.py:444-445, which tests/test_host_cpu.py expects of the drop-in too)."""
+    G = synth.GridSpec
+    for name, rows, cols in (('coord_1x3', 1, 3), ('coord_3x1', 3, 1), ('coord_1x1', 1, 1)):
+        run_case(name, G(rows=rows, cols=cols, tile_h=64, tile_w=96, ov_y=16, ov_x=24, seed=21, nz=2), use_registration=False)
+
+
 def main():
     if sys.argv[1:] == ['pyramid']:
         return pyramid_vectors()
+    if sys.argv[1:] == ['degenerate']:
+        return degenerate_cases()
     G = synth.GridSpec
     ch2 = synth.DEFAULT_CHANNELS[:2]
     # config 1: 2x2 of 512^2, coordinate-only (BASELINE.json configs[0])
@@ -340,6 +350,7 @@ def main():
     flatfield_vectors()
     normalize_vectors()
     pyramid_vectors()
+    degenerate_cases()
 
 
 if __name__ == '__main__':
