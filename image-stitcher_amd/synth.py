@@ -98,6 +98,7 @@ class GridSpec:
     base: int = 4096
     rgb_channels: Sequence[str] = ()   # channels written as H x W x 3 uint8 files (dtype must be uint8)
     missing: Sequence[Tuple[int, int, int, int]] = ()   # (fov, z, channel index, t) files NOT written (ragged input)
+    stage_jitter_um: float = 0.0     # coordinate-only tests: every FOV's stage position is off the grid by up to this
     sensor_pixel_size_um: float = 5.0
     magnification: float = 10.0
     tube_lens_mm: float = 180.0
@@ -133,6 +134,10 @@ class GridSpec:
         px = self.pixel_size_um
         x_mm = 10.0 + c * (self.tile_w - self.ov_x) * px / 1000
         y_mm = 20.0 + r * (self.tile_h - self.ov_y) * px / 1000
+        if self.stage_jitter_um:   # deterministic, different for every FOV and axis
+            h = int(hash2d(self.seed + 77, np.array([r]), np.array([c]))[0])
+            x_mm += ((h & 0xFFFF) / 65535.0 - 0.5) * 2 * self.stage_jitter_um / 1000
+            y_mm += (((h >> 16) & 0xFFFF) / 65535.0 - 0.5) * 2 * self.stage_jitter_um / 1000
         return x_mm, y_mm
 
     def scene_seed(self, region_idx: int, t: int, z: int, ch: int) -> int:

@@ -298,7 +298,27 @@ def degenerate_cases():
         run_case(name, G(rows=rows, cols=cols, tile_h=64, tile_w=96, ov_y=16, ov_x=24, seed=21, nz=2), use_registration=False)
 
 
+def more_cases():
+    """Added late in round 1: uint8 tiles with gains (clip at 255), S-Pattern with an even centre row,
+    a registration channel that does not exist (fallback to the first channel, stitcher.py:433-437), stage
+    positions off the grid in coordinate mode (every FOV has its own x and y: the int() truncations)."""
+    G = synth.GridSpec
+    ch2 = synth.DEFAULT_CHANNELS[:2]
+    run_case('reg_uint8_ff32', G(rows=2, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=23, dtype='uint8', noise=0,
+                                 channels=ch2),
+             use_registration=True, apply_flatfield=True, flat_dtype='float32')
+    run_case('reg_spattern_even', G(rows=5, cols=3, tile_h=128, tile_w=160, ov_y=36, ov_x=44, seed=24,
+                                    scan_pattern='S-Pattern', rev_ov_x=48, rev_jy=-2),
+             use_registration=True)
+    run_case('reg_missing_channel', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=25, channels=ch2),
+             use_registration=True, registration_channel='Fluorescence 730 nm Ex')
+    run_case('coord_jitter', G(rows=3, cols=4, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=26, nz=2, stage_jitter_um=3.7),
+             use_registration=False)
+
+
 def main():
+    if sys.argv[1:] == ['more']:
+        return more_cases()
     if sys.argv[1:] == ['pyramid']:
         return pyramid_vectors()
     if sys.argv[1:] == ['degenerate']:
@@ -351,6 +371,7 @@ def main():
     normalize_vectors()
     pyramid_vectors()
     degenerate_cases()
+    more_cases()
 
 
 if __name__ == '__main__':

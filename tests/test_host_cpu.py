@@ -127,8 +127,9 @@ def test_placement_matches_golden_and_oracle(name):
         shifts = placement.Shifts(tuple(info['h_shift']), tuple(info['v_shift']),
                                   tuple(info['h_shift_rev']) if 'h_shift_rev' in info else None,
                                   info.get('h_shift_rev_odd', 0))
-    xs = sorted(set(spec.stage_mm(0, c)[0] for c in range(spec.cols)))
-    ys = sorted(set(spec.stage_mm(r, 0)[1] for r in range(spec.rows)))
+    cells = [(r, c) for r in range(spec.rows) for c in range(spec.cols)]      # every FOV: positions may be off the grid
+    xs = sorted(set(spec.stage_mm(r, c)[0] for r, c in cells))
+    ys = sorted(set(spec.stage_mm(r, c)[1] for r, c in cells))
     wc, hc = placement.canvas_size(spec.cols, spec.rows, spec.tile_w, spec.tile_h,
                                    use_registration=p['use_registration'], shifts=shifts, xs=xs, ys=ys,
                                    pixel_size_um=spec.pixel_size_um)
