@@ -256,6 +256,11 @@ def normalize_vectors():
         d.dtype = np.dtype(dt).type
         arrays[f'in_{dt}'] = tile
         arrays[f'out_{dt}'] = np.asarray(ref_stitcher.Stitcher.normalize_image(d, tile))
+        # a constant tile: (img - min) / (max - min) is 0/0 everywhere; the cast of NaN decides the result
+        const = np.full((8, 12), 1234 % (np.iinfo(dt).max + 1), dtype=dt)
+        with np.errstate(all='ignore'):
+            arrays[f'const_in_{dt}'] = const
+            arrays[f'const_out_{dt}'] = np.asarray(ref_stitcher.Stitcher.normalize_image(d, const))
     np.savez_compressed(os.path.join(HERE, 'normalize_vectors.npz'), **arrays)
     print('[golden] normalize vectors written')
 
@@ -319,6 +324,8 @@ def more_cases():
 def main():
     if sys.argv[1:] == ['more']:
         return more_cases()
+    if sys.argv[1:] == ['normalize']:
+        return normalize_vectors()
     if sys.argv[1:] == ['pyramid']:
         return pyramid_vectors()
     if sys.argv[1:] == ['degenerate']:

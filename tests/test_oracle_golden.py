@@ -69,6 +69,9 @@ def test_normalize_image_golden():
         out = O.normalize_image(v[f'in_{dt}'], np.dtype(dt).type)
         assert out.dtype == np.dtype(dt)
         np.testing.assert_array_equal(out, v[f'out_{dt}'])
+        # constant tile: 0/0 -> NaN -> 0 through the reference's cast (recorded from the reference itself)
+        np.testing.assert_array_equal(O.normalize_image(v[f'const_in_{dt}'], np.dtype(dt).type), v[f'const_out_{dt}'])
+        assert not v[f'const_out_{dt}'].any()
 
 
 def test_flatfield_golden():

@@ -207,6 +207,8 @@ def test_normalize_tiles_equals_reference_golden_and_oracle():
     for dt in ('uint16', 'uint8'):
         got = native.normalize_tiles(torch.from_numpy(v[f'in_{dt}'][None]).to(_dev()))[0].cpu().numpy()
         np.testing.assert_array_equal(got, v[f'out_{dt}'])
+        got = native.normalize_tiles(torch.from_numpy(v[f'const_in_{dt}'][None]).to(_dev()))[0].cpu().numpy()
+        np.testing.assert_array_equal(got, v[f'const_out_{dt}'])       # constant tile: 0/0 -> 0
     rng = np.random.default_rng(6)
     stack = rng.integers(100, 60000, size=(5, 37, 61)).astype(np.uint16)
     stack[3] = 777                                   # max == min: 0/0 -> 0 like the reference's cast
