@@ -360,6 +360,12 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
         A[e] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
         const cplx d = {zk.re - zc.re, zk.im - zc.im};
         B[e] = {0.5 * d.im, -0.5 * d.re};
+        // A constant tile normalises to zeros (0/0 -> NaN -> 0, stitcher.py:613-617) and its spectrum is exactly
+        // zero in the reference; packed with the other image, the separation above would leave that image's
+        // rounding noise (1e-16 of its magnitude) in it, and with nothing else in the cross-power spectrum the
+        // noise would pick the peak.  (Golden case reg_blank_centre: the reference lands on index 0.)
+        if (rrange == 0.0) A[e] = {0.0, 0.0};
+        if (mrange == 0.0) B[e] = {0.0, 0.0};
     }
 }
 

@@ -98,6 +98,7 @@ class GridSpec:
     base: int = 4096
     rgb_channels: Sequence[str] = ()   # channels written as H x W x 3 uint8 files (dtype must be uint8)
     missing: Sequence[Tuple[int, int, int, int]] = ()   # (fov, z, channel index, t) files NOT written (ragged input)
+    blank_fovs: Sequence[int] = ()   # these FOVs are written as a constant image (cap on, empty well) in every plane
     stage_jitter_um: float = 0.0     # coordinate-only tests: every FOV's stage position is off the grid by up to this
     sensor_pixel_size_um: float = 5.0
     magnification: float = 10.0
@@ -207,6 +208,8 @@ def write_acquisition(spec: GridSpec, root: str, ext: str = 'tiff') -> List[str]
                                 continue
                             p = os.path.join(tdir, f'{region}_{fov}_{z}_{channel_file_token(ch)}.{ext}')
                             img = spec.tile(r, c, ri, t, z, ci)
+                            if fov in spec.blank_fovs:
+                                img = np.full_like(img, 500 % (int(np.iinfo(img.dtype).max) + 1))
                             if ch in spec.rgb_channels:   # three different planes of the same scene family
                                 img = np.stack([img, spec.tile(r, c, ri, t, z, ci + 17), spec.tile(r, c, ri, t, z, ci + 31)], axis=-1)
                             if ext in ('tiff', 'tif'):

@@ -317,6 +317,8 @@ def more_cases():
              use_registration=True)
     run_case('reg_missing_channel', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=25, channels=ch2),
              use_registration=True, registration_channel='Fluorescence 730 nm Ex')
+    run_case('reg_blank_centre', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=27, blank_fovs=(4,)),
+             use_registration=True)
     run_case('coord_jitter', G(rows=3, cols=4, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=26, nz=2, stage_jitter_um=3.7),
              use_registration=False)
 

@@ -28,7 +28,7 @@ def load_case(name):
 
 def spec_of(info):
     d = dict(info['spec'])
-    for k in ('channels', 'regions', 'rgb_channels'):
+    for k in ('channels', 'regions', 'rgb_channels', 'blank_fovs'):
         d[k] = tuple(d.get(k, ()))
     d['missing'] = tuple(tuple(m) for m in d.get('missing', ()))
     return synth.GridSpec(**d)
