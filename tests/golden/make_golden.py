@@ -182,11 +182,13 @@ def pcc_vectors():
     cases = []
     arrays = {}
     eps = np.finfo(np.float64).eps
-    shapes = [(64, 34), (34, 64), (256, 80), (80, 256), (96, 50), (45, 64), (1024, 256), (256, 1024)]
+    shapes = [(64, 34), (34, 64), (256, 80), (80, 256), (96, 50), (45, 64), (1024, 256), (256, 1024),
+              (63, 33), (50, 47), (64, 34), (33, 128), (128, 127)]   # odd widths; shifts near half the crop (wrap-around)
     for i, (n0, n1) in enumerate(shapes):
         seed = 4242 + i
-        dy, dx = [(3, -2), (-4, 5), (0, 0), (7, 1), (-1, -6), (2, 2), (5, -3), (-2, 4)][i]
-        big = synth.scene_patch(seed, 100, 100, n0 + 32, n1 + 32)
+        dy, dx = [(3, -2), (-4, 5), (0, 0), (7, 1), (-1, -6), (2, 2), (5, -3), (-2, 4),
+                  (4, -3), (-5, 6), (12, -11), (-9, 14), (1, -13)][i]
+        big = synth.scene_patch(seed, 100, 100, n0 + 32, n1 + 32)      # 16-px margin: |planted| <= 16
         ref = big[16:16 + n0, 16:16 + n1]
         mov = big[16 - dy:16 - dy + n0, 16 - dx:16 - dx + n1] + synth.noise_patch(seed + 1, n0, n1, 150)
         # min-max stretch as uint16, like the crops the stitcher hands to skimage
@@ -328,6 +330,8 @@ def main():
         return more_cases()
     if sys.argv[1:] == ['normalize']:
         return normalize_vectors()
+    if sys.argv[1:] == ['pcc']:
+        return pcc_vectors()
     if sys.argv[1:] == ['pyramid']:
         return pyramid_vectors()
     if sys.argv[1:] == ['degenerate']:
