@@ -321,6 +321,12 @@ def more_cases():
              use_registration=True, registration_channel='Fluorescence 730 nm Ex')
     run_case('reg_blank_centre', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=27, blank_fovs=(4,)),
              use_registration=True)
+    # pixel_binning 1: the crop width formula halves the overlap (odd width 21) and the shifts are whatever
+    # scikit-image makes of it -- deterministic all the same
+    run_case('reg_binning1', G(rows=3, cols=3, tile_h=128, tile_w=128, ov_y=40, ov_x=40, seed=28, pixel_binning=1),
+             use_registration=True)
+    run_case('reg_binning1_odd', G(rows=3, cols=3, tile_h=127, tile_w=131, ov_y=37, ov_x=43, seed=29, pixel_binning=1),
+             use_registration=True)
     run_case('coord_jitter', G(rows=3, cols=4, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=26, nz=2, stage_jitter_um=3.7),
              use_registration=False)
 

@@ -46,3 +46,8 @@ def flatfields_for(info, n_channels):
         ff = synth.synthetic_flatfield(sp['tile_h'], sp['tile_w'], dt)
         out[ci] = (ff * dt.type(1.0 + 0.03125 * ci)).astype(dt)
     return out
+
+
+# Cases whose crops do not contain the true overlap (pixel_binning 1 halves the crop width): the shifts are
+# whatever the correlation makes of unrelated crops, so the two normalisation modes need not agree there.
+PHASE_MAY_DIFFER = {'reg_binning1', 'reg_binning1_odd'}

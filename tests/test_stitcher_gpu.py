@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import REGION_CASES, flatfields_for, load_case, sha, spec_of
+from helpers import PHASE_MAY_DIFFER, REGION_CASES, flatfields_for, load_case, sha, spec_of
 from image_stitcher_amd import omezarr, synth
 from image_stitcher_amd.stitcher import Stitcher
 from image_stitcher_amd.stitcher_parameters import StitchingParameters
@@ -50,7 +50,15 @@ def test_stitcher_matches_reference(name, tmp_path):
         # the scikit-image >= 0.19 default recovers the same integers on these scenes
         st2 = _prepared(info, root, normalization='phase')
         st2.calculate_shifts(st2.timepoints[0], st2.regions[0])
-        assert (list(st2.h_shift), list(st2.v_shift)) == (info['h_shift'], info['v_shift'])
+        if name in PHASE_MAY_DIFFER:     # ... but there the device agrees with the oracle's phase mode
+            from image_stitcher_amd.tiffio import read_image
+            from oracle import stitch_oracle as O
+            acq = O.parse_acquisition(root, read_image)
+            ph = O.calculate_shifts(acq, acq.timepoints[0], acq.regions[0], read_image, info['params']['registration_channel'],
+                                    info['params']['registration_z_level'], spec.scan_pattern, normalization='phase')
+            assert (tuple(st2.h_shift), tuple(st2.v_shift)) == (tuple(ph['h_shift']), tuple(ph['v_shift']))
+        else:
+            assert (list(st2.h_shift), list(st2.v_shift)) == (info['h_shift'], info['v_shift'])
     for key, cinfo in info['canvases'].items():
         t, region = key[1:].split('_', 1)
         canvas = st.stitch_region(int(t), region)
