@@ -171,3 +171,16 @@ def filename_order(fovs: Sequence[int]) -> List[int]:
     plane: file names ``{region}_{fov}_{z}_{channel}`` sort as strings (stitcher.py:168), and
     '_' sorts after the digits, so fov 10 comes before fov 1, which comes before fov 2."""
     return sorted(range(len(fovs)), key=lambda i: f"{fovs[i]}_")
+
+
+def check_rect_fits_like_numpy(rect, canvas_h: int, canvas_w: int) -> None:
+    """The reference clips a tile to the canvas with ``tile[:y_end - y, :x_end - x]`` (stitcher.py:589-598).  When a
+    tile starts beyond the canvas edge the slice end is negative, python counts it from the tile's other end,
+    and the assignment dies with numpy's broadcast ValueError.  Garbage shifts only -- but the same input must
+    fail the same way here, so this re-enacts the two slices and raises that error."""
+    _, _, h, w, dy, dx = (int(v) for v in rect)
+    y_end, x_end = min(dy + h, canvas_h), min(dx + w, canvas_w)
+    tile_rows, tile_cols = len(range(h)[:y_end - dy]), len(range(w)[:x_end - dx])
+    dst_rows, dst_cols = len(range(canvas_h)[dy:y_end]), len(range(canvas_w)[dx:x_end])
+    if (tile_rows, tile_cols) != (dst_rows, dst_cols):
+        raise ValueError(f"could not broadcast input array from shape ({tile_rows},{tile_cols}) into shape ({dst_rows},{dst_cols})")

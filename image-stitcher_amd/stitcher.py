@@ -588,6 +588,7 @@ class Stitcher:
         for key, info in region_data.items():
             _, _, fov, z_level, channel = key
             rect = self._tile_rect(info)
+            placement.check_rect_fits_like_numpy(rect, height, width)
             if channel in self.monochrome_channels:
                 targets = [(self.monochrome_channels.index(channel) * self.num_z + z_level, -1)]
             else:   # RGB file -> three monochrome channels (stitcher.py:551-556)

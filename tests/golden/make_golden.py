@@ -86,7 +86,7 @@ class Recorder:
 
 
 def run_case(name, spec, *, use_registration, apply_flatfield=False, flat_dtype=None,
-             registration_channel='', registration_z_level=0, keep_canvas=True, windows=()):
+             registration_channel='', registration_z_level=0, keep_canvas=True, windows=(), forced=None):
     tmp = tempfile.mkdtemp(prefix='golden_')
     root = os.path.join(tmp, 'acq')
     try:
@@ -111,7 +111,14 @@ def run_case(name, spec, *, use_registration, apply_flatfield=False, flat_dtype=
                 # make channels differ a little, deterministically
                 st.flatfields[ci] = (ff * np.dtype(flat_dtype).type(1.0 + 0.03125 * ci)).astype(flat_dtype)
         if use_registration:
-            st.calculate_shifts(st.timepoints[0], st.regions[0])
+            if forced is None:
+                st.calculate_shifts(st.timepoints[0], st.regions[0])
+            else:   # shifts dictated, not measured: the reference's geometry code on arbitrary integers
+                st.h_shift, st.v_shift = tuple(forced[0]), tuple(forced[1])
+                if len(forced) > 2:
+                    st.h_shift_rev, st.h_shift_rev_odd = tuple(forced[2]), forced[3]
+                st.calculate_output_dimensions(st.timepoints[0], st.regions[0])   # sets x/y_positions as calculate_shifts would
+                out['forced'] = True
             out['h_shift'] = [int(v) for v in st.h_shift]
             out['v_shift'] = [int(v) for v in st.v_shift]
             if spec.scan_pattern == 'S-Pattern':
@@ -331,7 +338,27 @@ def more_cases():
              use_registration=False)
 
 
+def forced_cases():
+    """The reference's integer geometry (canvas size, placement, crops, clip: stitcher.py:298-354, 563-605,
+    639-689) driven with dictated shifts of every sign combination -- including ones no registration of real
+    tiles would return (positive 'overlaps', large skews): floor division on negatives, abs() here but not
+    there, int() truncation."""
+    G = synth.GridSpec
+    combos = [((5, -20), (-20, -3)), ((-4, -18), (-22, 6)), ((0, 10), (12, 0)), ((7, 0), (0, -7)), ((-9, 15), (-14, -11)),
+              ((11, -31), (9, 13)), ((-1, -1), (-1, -1)), ((0, 0), (0, 0)), ((3, -79), (-63, -2))]
+    for k, (h, v) in enumerate(combos):
+        try:
+            run_case(f'forced_{k}', G(rows=3, cols=4, tile_h=64, tile_w=80, ov_y=16, ov_x=20, seed=40 + k, nz=1),
+                     use_registration=True, forced=(h, v))
+        except Exception as exc:      # the reference itself cannot place tiles with these shifts
+            print(f'[golden] forced_{k} {h} {v}: reference raises {type(exc).__name__}: {exc}')
+    run_case('forced_spattern', G(rows=4, cols=3, tile_h=64, tile_w=80, ov_y=16, ov_x=20, seed=60, scan_pattern='S-Pattern'),
+             use_registration=True, forced=((4, -22), (-17, 3), (-3, -25), True))
+
+
 def main():
+    if sys.argv[1:] == ['forced']:
+        return forced_cases()
     if sys.argv[1:] == ['more']:
         return more_cases()
     if sys.argv[1:] == ['normalize']:
@@ -391,6 +418,7 @@ def main():
     pyramid_vectors()
     degenerate_cases()
     more_cases()
+    forced_cases()
 
 
 if __name__ == '__main__':

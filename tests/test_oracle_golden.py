@@ -96,7 +96,11 @@ def test_region_case(name, tmp_path):
     assert acq.num_z == info['num_z']
     assert str(np.dtype(acq.dtype)) == info['dtype']
     shifts = None
-    if p['use_registration']:
+    if info.get('forced'):      # dictated shifts: the reference's integer geometry on arbitrary sign combinations
+        shifts = dict(h_shift=tuple(info['h_shift']), v_shift=tuple(info['v_shift']))
+        if 'h_shift_rev' in info:
+            shifts.update(h_shift_rev=tuple(info['h_shift_rev']), h_shift_rev_odd=info['h_shift_rev_odd'])
+    elif p['use_registration']:
         shifts = O.calculate_shifts(acq, acq.timepoints[0], acq.regions[0], read_image,
                                     p['registration_channel'], p['registration_z_level'],
                                     spec.scan_pattern, normalization=None)
