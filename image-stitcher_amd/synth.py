@@ -98,6 +98,7 @@ class GridSpec:
     base: int = 4096
     rgb_channels: Sequence[str] = ()   # channels written as H x W x 3 uint8 files (dtype must be uint8)
     missing: Sequence[Tuple[int, int, int, int]] = ()   # (fov, z, channel index, t) files NOT written (ragged input)
+    region_dims: Sequence[Tuple[str, int, int]] = ()   # (region, rows, cols) for regions whose grid is not rows x cols
     blank_fovs: Sequence[int] = ()   # these FOVs are written as a constant image (cap on, empty well) in every plane
     stage_jitter_um: float = 0.0     # coordinate-only tests: every FOV's stage position is off the grid by up to this
     sensor_pixel_size_um: float = 5.0
@@ -115,11 +116,19 @@ class GridSpec:
     def n_tiles(self) -> int:
         return self.rows * self.cols
 
+    def dims_of(self, region: str) -> Tuple[int, int]:
+        """(rows, cols) of one region's grid (plates whose edge wells hold fewer FOVs)."""
+        for name, rows, cols in self.region_dims:
+            if name == region:
+                return int(rows), int(cols)
+        return self.rows, self.cols
+
     def row_reversed(self, r: int) -> bool:
         return self.scan_pattern == 'S-Pattern' and (r % 2 == 1)
 
-    def fov_index(self, r: int, c: int) -> int:
-        return r * self.cols + (self.cols - 1 - c if self.row_reversed(r) else c)
+    def fov_index(self, r: int, c: int, cols: Optional[int] = None) -> int:
+        cols = self.cols if cols is None else cols
+        return r * cols + (cols - 1 - c if self.row_reversed(r) else c)
 
     def origin(self, r: int, c: int) -> Tuple[int, int]:
         ov_x, jy = self.ov_x, self.jy
@@ -197,9 +206,10 @@ def write_acquisition(spec: GridSpec, root: str, ext: str = 'tiff') -> List[str]
         os.makedirs(tdir, exist_ok=True)
         lines = ['region,fov,z_level,x (mm),y (mm),z (um)']
         for ri, region in enumerate(spec.regions):
-            for r in range(spec.rows):
-                for c in range(spec.cols):
-                    fov = spec.fov_index(r, c)
+            rows, cols = spec.dims_of(region)
+            for r in range(rows):
+                for c in range(cols):
+                    fov = spec.fov_index(r, c, cols)
                     x_mm, y_mm = spec.stage_mm(r, c)
                     for z in range(spec.nz):
                         lines.append(f'{region},{fov},{z},{x_mm!r},{y_mm!r},{z * spec.dz_um!r}')
@@ -244,7 +254,8 @@ def write_acquisition_device(spec: GridSpec, root: str, device, workers: int = 1
             os.makedirs(tdir, exist_ok=True)
             lines = ['region,fov,z_level,x (mm),y (mm),z (um)']
             for ri, region in enumerate(spec.regions):
-                cells = [(r, c, spec.fov_index(r, c)) for r in range(spec.rows) for c in range(spec.cols)]
+                rows, cols = spec.dims_of(region)
+                cells = [(r, c, spec.fov_index(r, c, cols)) for r in range(rows) for c in range(cols)]
                 for r, c, fov in cells:
                     x_mm, y_mm = spec.stage_mm(r, c)
                     for z in range(spec.nz):

@@ -334,6 +334,13 @@ def more_cases():
              use_registration=True)
     run_case('reg_binning1_odd', G(rows=3, cols=3, tile_h=127, tile_w=131, ov_y=37, ov_x=43, seed=29, pixel_binning=1),
              use_registration=True)
+    # a plate whose wells hold different grids (edge wells with fewer FOVs): shifts measured on the first well
+    run_case('reg_unequal_wells', G(rows=3, cols=3, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=30, regions=('A1', 'A2', 'B1'),
+                                    region_dims=(('A2', 2, 3), ('B1', 3, 2)), channels=ch2),
+             use_registration=True)
+    run_case('coord_unequal_wells', G(rows=3, cols=3, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=31, regions=('A1', 'B2'),
+                                      region_dims=(('B2', 1, 2),), nt=2),
+             use_registration=False)
     run_case('coord_jitter', G(rows=3, cols=4, tile_h=96, tile_w=128, ov_y=24, ov_x=40, seed=26, nz=2, stage_jitter_um=3.7),
              use_registration=False)
 

@@ -31,6 +31,7 @@ def spec_of(info):
     for k in ('channels', 'regions', 'rgb_channels', 'blank_fovs'):
         d[k] = tuple(d.get(k, ()))
     d['missing'] = tuple(tuple(m) for m in d.get('missing', ()))
+    d['region_dims'] = tuple(tuple(m) for m in d.get('region_dims', ()))
     return synth.GridSpec(**d)
 
 

@@ -127,27 +127,29 @@ def test_placement_matches_golden_and_oracle(name):
         shifts = placement.Shifts(tuple(info['h_shift']), tuple(info['v_shift']),
                                   tuple(info['h_shift_rev']) if 'h_shift_rev' in info else None,
                                   info.get('h_shift_rev_odd', 0))
-    cells = [(r, c) for r in range(spec.rows) for c in range(spec.cols)]      # every FOV: positions may be off the grid
-    xs = sorted(set(spec.stage_mm(r, c)[0] for r, c in cells))
-    ys = sorted(set(spec.stage_mm(r, c)[1] for r, c in cells))
-    wc, hc = placement.canvas_size(spec.cols, spec.rows, spec.tile_w, spec.tile_h,
-                                   use_registration=p['use_registration'], shifts=shifts, xs=xs, ys=ys,
-                                   pixel_size_um=spec.pixel_size_um)
     for key, cinfo in info['canvases'].items():
+        region = key[1:].split('_', 1)[1]
+        rows, cols = spec.dims_of(region)                                         # wells may hold different grids
+        cells = [(r, c) for r in range(rows) for c in range(cols)]                # every FOV: positions may be off the grid
+        xs = sorted(set(spec.stage_mm(r, c)[0] for r, c in cells))
+        ys = sorted(set(spec.stage_mm(r, c)[1] for r, c in cells))
+        wc, hc = placement.canvas_size(cols, rows, spec.tile_w, spec.tile_h,
+                                       use_registration=p['use_registration'], shifts=shifts, xs=xs, ys=ys,
+                                       pixel_size_um=spec.pixel_size_um)
         assert cinfo['shape'][3:] == [hc, wc]
         gold = arrays[f'{key}_placements']          # (c, z, x_pixel, y_pixel, row, col) BEFORE the crop offset
         for c, z, x_px, y_px, row, col in gold:
             if p['use_registration']:
-                sy, sx, h, w, dy, dx = placement.registered_rect(int(row), int(col), spec.rows, spec.cols,
+                sy, sx, h, w, dy, dx = placement.registered_rect(int(row), int(col), rows, cols,
                                                                  spec.tile_w, spec.tile_h, shifts)
                 assert (dy - sy, dx - sx) == (y_px, x_px)
         if not p['use_registration']:
             # coordinate mode: rebuild from stage positions in sorted-filename order
-            fovs = [spec.fov_index(r, c) for r in range(spec.rows) for c in range(spec.cols)]
+            fovs = [spec.fov_index(r, c, cols) for r, c in cells]
             order = placement.filename_order(fovs)
             per_plane = gold[(gold[:, 0] == 0) & (gold[:, 1] == 0)]
             for k, i in enumerate(order):
-                r, c = divmod(i, spec.cols)
+                r, c = divmod(i, cols)
                 x_mm, y_mm = spec.stage_mm(r, c)
                 rect = placement.coordinate_rect(x_mm, y_mm, min(xs), min(ys), spec.tile_w, spec.tile_h, spec.pixel_size_um)
                 assert (rect[5], rect[4]) == (per_plane[k][2], per_plane[k][3])
