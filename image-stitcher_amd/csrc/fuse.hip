@@ -825,7 +825,7 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
 // Persistent launch: as many workgroups as the chip keeps resident (queried once per kernel),
 // each walking the (plane, item) list with a grid stride.
 template <typename K>
-int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream) {
+int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream, int grid_override = 0) {
     const int64_t n_work = n_items * n_planes;
     if (n_work == 0) return SQ_OK;
     static thread_local std::map<const void *, int> resident;
@@ -839,7 +839,6 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         it = resident.emplace(key, cus * std::min(per_cu, 8)).first;
     }
-    const int grid_override = getenv("SQ_FUSE_GRID") ? atoi(getenv("SQ_FUSE_GRID")) : 0;
     const int64_t blocks = std::min<int64_t>(n_work, grid_override > 0 ? grid_override : it->second);
     // work-queue chunk: QUEUE_CHUNK items per atomic when every workgroup gets many chunks, fewer for small
     // launches so that the last round does not leave workgroups idle
@@ -987,6 +986,9 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
     if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
+    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC)) || a->grid_blocks < 0 ||
+        ((a->flags & SQ_FUSE_FORCE_QUEUES) && (a->flags & SQ_FUSE_FORCE_STATIC)))
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: flags %d / grid_blocks %d", a->flags, a->grid_blocks);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
         return fail(SQ_ERR_UNSUPPORTED, "sq_fuse_planes: tile dtype %d (uint8/uint16 only)", a->tile_dtype);
     if (a->flat_ptrs_dev && a->flat_dtype != SQ_F32 && a->flat_dtype != SQ_F64)
@@ -1040,8 +1042,8 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         // the queues count in 32 bits; a launch with fewer than ~64 items per resident workgroup is over
         // before the queues pay for their barriers (measured on the 8x8-grid, one-plane case): static walk
         const int64_t n_work = (int64_t)a->n_planes * h.n_items;
-        // (SQ_FUSE_QUEUE=1 forces the queues whatever the size -- tests; SQ_FUSE_STATIC=1 the static walk)
-        if ((n_work >= 100000 || getenv("SQ_FUSE_QUEUE")) && n_work < (int64_t(1) << 31) && !getenv("SQ_FUSE_STATIC"))
+        // (args->flags can force either one whatever the size -- tests)
+        if ((n_work >= 100000 || (a->flags & SQ_FUSE_FORCE_QUEUES)) && n_work < (int64_t(1) << 31) && !(a->flags & SQ_FUSE_FORCE_STATIC))
             P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + (((int64_t)a->n_planes * 4 + 127) & ~int64_t(127)));
     }
     const bool u16 = a->tile_dtype == SQ_U16;
@@ -1052,8 +1054,8 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
                         a->canvas_dtype, a->tile_dtype);
 #define SQ_OVERWRITE(T, F)                                                                                  \
     do {                                                                                                      \
-        if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream);     \
-        return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream);                 \
+        if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);     \
+        return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                 \
     } while (0)
         if (u16) {
             if (flat == 0) SQ_OVERWRITE(uint16_t, 0);
@@ -1071,8 +1073,8 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: feather canvas must be float32 or the tile dtype");
 #define SQ_FEATHER_F(T, O, F)                                                                              \
     do {                                                                                                    \
-        if (P.queue) return launch(fuse_feather_kernel<T, O, F, true>, P, h.n_items, a->n_planes, stream);  \
-        return launch(fuse_feather_kernel<T, O, F, false>, P, h.n_items, a->n_planes, stream);              \
+        if (P.queue) return launch(fuse_feather_kernel<T, O, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);  \
+        return launch(fuse_feather_kernel<T, O, F, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);              \
     } while (0)
 #define SQ_FEATHER(T, O)                 \
     do {                                 \

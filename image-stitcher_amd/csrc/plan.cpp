@@ -287,8 +287,13 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     // [0, 8 * lane_items) are interleaved this way (header field); the lanes' leftovers and the zero-fill
     // items follow.  Every item still moves whole row segments, so HBM sees the same contiguous runs, in
     // a different order.
-    //   SQ_PLAN_ORDER=0 keeps span order, 1 = row blocks without the XCD interleave (experiments).
+    //   (experiment builds only, -DSQ_EXPERIMENTS: SQ_PLAN_ORDER=0 keeps span order, 1 = row blocks
+    //   without the XCD interleave; the product library reads no environment variable)
+#ifdef SQ_EXPERIMENTS
     const char *order_env = getenv("SQ_PLAN_ORDER");
+#else
+    const char *order_env = nullptr;
+#endif
     const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : 0;
     constexpr int NX = 8;
     const int nblk = tile_h / BLOCK_ROWS + 2;   // row blocks, +1 slack, +1 for the zero-fill bucket
@@ -396,11 +401,15 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     }
     const auto t_order = std::chrono::steady_clock::now();
     const size_t n_spans_dbg = spans.size();
+#ifdef SQ_EXPERIMENTS
     if (getenv("SQ_PLAN_TIMING")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[plan] sweep %.3f ms, count %.3f ms, emit %.3f ms (%zu spans, %lld items)\n",
                 ms(t_begin, t_sweep), ms(t_sweep, t_items), ms(t_items, t_order), n_spans_dbg, (long long)n_items);
     }
+#else
+    (void)t_begin; (void)t_sweep; (void)t_items; (void)t_order; (void)n_spans_dbg;
+#endif
     return plan;
 }
 

@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get('SQ_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsqui
 SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
+SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC = 1, 2
+SQ_VERSION = 101
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
                        ('dst_y', '<i4'), ('dst_x', '<i4')])
@@ -46,6 +48,7 @@ class _FuseArgs(C.Structure):
         ('canvas_h', C.c_int32), ('canvas_w', C.c_int32), ('canvas_pitch', C.c_int32),
         ('canvas_dtype', C.c_int32), ('n_planes', C.c_int32), ('mode', C.c_int32),
         ('scratch_dev', C.c_void_p), ('scratch_bytes', C.c_int64),
+        ('flags', C.c_int32), ('grid_blocks', C.c_int32),
     ]
 
 
@@ -106,6 +109,8 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.sq_version() != SQ_VERSION:
+            raise NativeError(f"{LIB_PATH} is version {handle.sq_version()}, this binding expects {SQ_VERSION}: rebuild it")
         _lib = handle
     return _lib
 
@@ -195,14 +200,17 @@ class FusePlan:
         import torch
         key = str(device)
         if key not in self._dev:
-            dev = torch.empty(max(self.table_bytes, 1), dtype=torch.uint8, device=device)
             # on the read-back / upload stream, not the caller's: the copy must not queue behind a fusion
             # launch that is still running there (the entry point waits for the copy, so the table is
-            # complete before anything later is launched)
+            # complete before anything later is launched).  The block comes from THAT stream's pool (see
+            # _side_empty): a block of the caller's pool could still be read by a running fusion kernel.
+            dev = _side_empty((max(self.table_bytes, 1),), torch.uint8, torch.device(device))
             with torch.cuda.device(dev.device):
                 side = _copy_stream(dev.device)
                 _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr(side)), 'sq_fuse_plan_upload')
             self._dev[key] = dev
+        else:
+            self._dev[key].record_stream(torch.cuda.current_stream(self._dev[key].device))
         return self._dev[key]
 
     def close(self) -> None:
@@ -217,16 +225,33 @@ class FusePlan:
             pass
 
 
+def _side_empty(shape, dtype, device):
+    """Device tensor that is WRITTEN on the copy stream and READ by kernels on the caller's stream.
+
+    The block is taken from the copy stream's pool and ``record_stream``-ed for the caller's stream, so the
+    caching allocator hands it out again only after the caller-stream work enqueued up to the moment it is
+    dropped has finished -- and then only to another copy-stream allocation.  (Allocated from the caller's
+    pool instead, a dropped block would be reused by the next upload at once and overwritten from the copy
+    stream while a fusion kernel launched earlier is still reading it.)"""
+    import torch
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    with torch.cuda.stream(_copy_stream(device)):
+        t = torch.empty(shape, dtype=dtype, device=device)
+    t.record_stream(torch.cuda.current_stream(device))
+    return t
+
+
 def upload_small(host, device):
     """A small host tensor -> device, copied on the read-back / upload stream instead of the caller's: a
     pageable host-to-device copy blocks the host until everything queued before it on ITS stream is done,
     and on the caller's stream that can be a 35 ms fusion launch.  Returns when the data is on the device."""
     import torch
-    device = torch.device(device)
-    dst = torch.empty(host.shape, dtype=host.dtype, device=device)
+    dst = _side_empty(tuple(host.shape), host.dtype, device)
     if dst.numel():
-        with torch.cuda.stream(_copy_stream(device)):
-            dst.copy_(host)
+        with torch.cuda.stream(_copy_stream(dst.device)):
+            dst.copy_(host)      # pageable source: returns when the bytes are on the device
     return dst
 
 
@@ -237,7 +262,8 @@ def pointer_table(tensors: Sequence, device):
     return upload_small(torch.tensor(ptrs, dtype=torch.int64), device)
 
 
-def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, stream=None, flat_ptrs=None) -> None:
+def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, stream=None, flat_ptrs=None,
+                flags: int = 0, grid_blocks: int = 0) -> None:
     """Fuse all planes of ``canvas`` ([P, Hc, Wc] or [..., Hc, Wc] contiguous) from ``tiles``.
 
     tiles:     contiguous device tensor [P, N, H, W] (N = plan.n_tiles), or None with
@@ -308,6 +334,10 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
     a.canvas_dtype = sq_dtype_of(np_dtype_of_torch(canvas.dtype))
     a.n_planes = n_planes
     a.mode = plan.mode
+    a.flags, a.grid_blocks = int(flags), int(grid_blocks)
+    if stream is not None:      # launched on another stream than the one the helpers above allocated for
+        for t in keep:
+            t.record_stream(stream)
     _check(L.sq_fuse_planes(C.byref(a), _stream_ptr(stream)), 'sq_fuse_planes')
 
 

@@ -638,6 +638,9 @@ class Stitcher:
             writer = stream_to(max(1, min(max(len(pl) for pl in groups.values()), budget // max(1, widest))))
         try:
             for sig, plist in groups.items():
+                # ascending plane ids: the canvas slots of a chunk are then consecutive and the whole chunk
+                # goes out in ONE launch (region_data is in file-name order, i.e. z varies before channel)
+                plist = sorted(plist)
                 rects = rect_of[sig]
                 n = len(rects)
                 plan = self._plan_for(rects, th, tw, hc, wc, mode)
@@ -651,10 +654,12 @@ class Stitcher:
                 bufs = self._buffer_cache.get(key)
                 if bufs is None:   # pinned staging + device mirrors, kept for the next region of the same shape
                     bufs = ([torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)],
-                            [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)])
+                            [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)],
+                            [None] * n_slots)
                     self._keep_buffers(key, bufs)
-                staging, on_dev = bufs
-                done = [None] * n_slots
+                # the slots' "copy and fusion finished" events live with the buffers: another group (or the next
+                # region) that gets the same cached staging must wait for the H2D copy still reading it
+                staging, on_dev, done = bufs
                 for k, chunk in enumerate(chunks):
                     slot = k % n_slots
                     if done[slot] is not None:
@@ -788,14 +793,16 @@ class Stitcher:
                        name=f"{region}_t{timepoint}")
         return output_path
 
-    def _write_shift_table(self, n_units, my_rows, rank, world, coll) -> None:
+    def _write_shift_table(self, n_units, my_rows, rank, world, coll, shared: bool = False) -> None:
         """``shift_table.json`` in the output folder: the shifts every (timepoint, region) was fused with.
         With per-region registration every rank contributes the rows it measured: one all-gather of
         ceil(units / world) rows of 8 int32 per rank (RCCL over xGMI with the nccl backend) -- the only
         collective on the path."""
         units = [(int(t), region) for t in self.timepoints for region in self.regions]
         if self.per_region_registration:
-            per_rank = -(-n_units // world)
+            # rows any rank can hold: its block-cyclic share of the units -- or all of them on rank 0 when the
+            # ranks share every region plane by plane (fewer units than GPUs) and rank 0 registers each
+            per_rank = n_units if shared else -(-n_units // world)
             local = np.zeros((per_rank, sharding.SHIFT_ROW), dtype=np.int32)
             index = np.full(per_rank, -1, dtype=np.int64)
             for slot, (i, row) in enumerate(sorted(my_rows.items())):
@@ -911,7 +918,7 @@ class Stitcher:
                 output_path = self.save_region_aics(timepoint, region, stitched_region)
             print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
         if self.use_registration:
-            self._write_shift_table(n_units, my_rows, rank, world, coll)
+            self._write_shift_table(n_units, my_rows, rank, world, coll, shared)
         sharding.barrier()
         self.starting_saving.emit(True)
         if self.merge_timepoints or self.merge_hcs_regions:

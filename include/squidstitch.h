@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 100 /* 0.1.0 */
+#define SQ_VERSION 101 /* 0.1.1: sq_fuse_args grew flags / grid_blocks */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -117,7 +117,16 @@ typedef struct sq_fuse_args {
     /* through per-XCD device queues; NULL = generic divide, static work split                          */
     void *scratch_dev;
     int64_t scratch_bytes;
+    /* work distribution: 0 = the library chooses (device queues for big launches, a static walk for     */
+    /* small ones); tests force either one.  grid_blocks > 0 caps the persistent grid (0 = resident WGs) */
+    int32_t flags; /* sq_fuse_flags */
+    int32_t grid_blocks;
 } sq_fuse_args;
+
+typedef enum sq_fuse_flags {
+    SQ_FUSE_FORCE_QUEUES = 1, /* device work queues whatever the launch size (needs scratch_dev) */
+    SQ_FUSE_FORCE_STATIC = 2  /* static grid-stride walk whatever the launch size                */
+} sq_fuse_flags;
 
 int64_t sq_fuse_scratch_bytes(int32_t n_planes);
 

@@ -18,7 +18,7 @@ def _torch():
 
 
 def run_fuse(rects, tiles_np, ch, cw, mode=native.SQ_FUSE_OVERWRITE, flats_np=None, out_dtype=None, use_ptrs=False,
-             n_planes=1):
+             n_planes=1, flags=0):
     torch = _torch()
     dev = torch.device('cuda:0')
     th, tw = tiles_np.shape[-2:]
@@ -32,9 +32,10 @@ def run_fuse(rects, tiles_np, ch, cw, mode=native.SQ_FUSE_OVERWRITE, flats_np=No
     if use_ptrs:
         flat_list = tiles.reshape(-1, th, tw)
         ptrs = native.pointer_table([flat_list[i] for i in range(flat_list.shape[0])], dev)
-        native.fuse_planes(plan, None if mode == native.SQ_FUSE_OVERWRITE else tiles, canvas, flats, tile_ptrs=ptrs)
+        native.fuse_planes(plan, None if mode == native.SQ_FUSE_OVERWRITE else tiles, canvas, flats, tile_ptrs=ptrs,
+                           flags=flags)
     else:
-        native.fuse_planes(plan, tiles, canvas, flats)
+        native.fuse_planes(plan, tiles, canvas, flats, flags=flags)
     torch.cuda.synchronize()
     return canvas.cpu().numpy(), plan
 
@@ -277,11 +278,11 @@ def test_fast_and_generic_divide_agree_on_real_planes(dtype):
 
 @pytest.mark.parametrize('queues', [False, True])
 @pytest.mark.parametrize('seed', range(24))
-def test_fuzz_geometry_dtype_flat_mode(seed, queues, monkeypatch):
+def test_fuzz_geometry_dtype_flat_mode(seed, queues):
     """Random tile sizes (down to a few pixels: rows shorter than one 16-byte vector), canvas pitches,
     rectangle counts, dtypes, flatfield precisions, plane counts and both fusion modes; the kernels
     with their static walk (what launches this small take) and with the device work queues forced."""
-    monkeypatch.setenv('SQ_FUSE_QUEUE' if queues else 'SQ_FUSE_STATIC', '1')
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
     rng = np.random.default_rng(1000 + seed)
     dtype = ['uint16', 'uint8'][seed % 2]
     th, tw = int(rng.integers(1, 70)), int(rng.integers(1, 300))
@@ -310,13 +311,14 @@ def test_fuzz_geometry_dtype_flat_mode(seed, queues, monkeypatch):
     feather = seed % 4 == 3 and n > 0
     if feather:
         out_dtype = [dtype, 'float32'][seed % 8 == 7]
-        got, _ = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=flats, out_dtype=out_dtype, n_planes=planes)
+        got, _ = run_fuse(rects, tiles, ch, cw, mode=native.SQ_FUSE_FEATHER, flats_np=flats, out_dtype=out_dtype, n_planes=planes,
+                          flags=flags)
         for p in range(planes):
             want = O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None if flats is None else flats[p],
                                         out_dtype=np.dtype(out_dtype).type) if n else np.zeros((ch, cw), out_dtype)
             np.testing.assert_array_equal(got[p], want)
     else:
-        got, plan = run_fuse(rects, tiles, ch, cw, flats_np=flats, n_planes=planes)
+        got, plan = run_fuse(rects, tiles, ch, cw, flats_np=flats, n_planes=planes, flags=flags)
         for p in range(planes):
             want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, None if flats is None else flats[p]) if n \
                 else np.zeros((ch, cw), dtype)
@@ -382,10 +384,9 @@ def test_padded_tile_and_canvas_pitches_through_the_c_abi():
 
 
 @pytest.mark.parametrize('planes', [1, 3])
-def test_work_queues_on_a_registered_grid(planes, monkeypatch):
+def test_work_queues_on_a_registered_grid(planes):
     """The per-XCD queues on a lane-interleaved plan (registered 5x6 grid, cropped tiles, float32 gains, several
     planes): chunks that straddle planes, lanes of unequal length, the rest queue and stealing all occur."""
-    monkeypatch.setenv('SQ_FUSE_QUEUE', '1')
     from image_stitcher_amd import placement
     rng = np.random.default_rng(99)
     th, tw = 72, 200
@@ -394,7 +395,7 @@ def test_work_queues_on_a_registered_grid(planes, monkeypatch):
     wc, hc = placement.canvas_size(5, 6, tw, th, use_registration=True, shifts=s)
     tiles = rng.integers(0, 65536, size=(planes, 30, th, tw)).astype(np.uint16)
     flats = [(0.5 + rng.random((th, tw))).astype(np.float32) for _ in range(planes)]
-    got, plan = run_fuse(rects, tiles, hc, wc, flats_np=flats, n_planes=planes)
+    got, plan = run_fuse(rects, tiles, hc, wc, flats_np=flats, n_planes=planes, flags=native.SQ_FUSE_FORCE_QUEUES)
     assert plan.n_items > 64
     for p in range(planes):
         np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(tiles[p]), rects, hc, wc, flats[p]))

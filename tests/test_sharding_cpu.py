@@ -90,3 +90,44 @@ def test_world_size_2_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = np.load(tmp_path / 'ok0.npy'), np.load(tmp_path / 'ok1.npy')
     np.testing.assert_array_equal(a, b)      # every rank ends with the same table
+
+
+def _shift_table_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from image_stitcher_amd import sharding as sh
+        from image_stitcher_amd.placement import Shifts as S
+        from image_stitcher_amd.stitcher import Stitcher
+        st = object.__new__(Stitcher)       # only the writer's inputs; no dataset, no device
+        st.timepoints, st.regions = [0], ['A1', 'A2']
+        st.per_region_registration = True
+        st.output_folder = out_dir
+        st.scan_pattern = 'Unidirectional'
+        # fewer units (2) than ranks (3), shared by planes: rank 0 measured BOTH units, the others none
+        rows = {i: sh.shifts_to_row(S((i, -100 - i), (-200 - i, i))) for i in range(2)} if rank == 0 else {}
+        st._write_shift_table(2, rows, rank, world, None, shared=True)
+        # units dealt block-cyclically (5 units, 3 ranks): ceil(5/3) = 2 rows per rank
+        st.regions = ['A1', 'A2', 'A3', 'A4', 'A5']
+        st.output_folder = os.path.join(out_dir, 'dealt')
+        if rank == 0:
+            os.makedirs(st.output_folder, exist_ok=True)
+        dist.barrier()
+        rows = {i: sh.shifts_to_row(S((i, -100 - i), (-200 - i, i))) for i in sh.block_cyclic(5, rank, world)}
+        st._write_shift_table(5, rows, rank, world, None, shared=False)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shift_table_json_shared_region_three_ranks(tmp_path):
+    """2 units on 3 ranks (regions shared by planes) overflowed rank 0's gather buffer."""
+    import json
+    port = _free_port()
+    mp.spawn(_shift_table_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for folder, n in ((tmp_path, 2), (tmp_path / 'dealt', 5)):
+        with open(folder / 'shift_table.json') as fh:
+            doc = json.load(fh)
+        assert doc['per_region_registration'] is True and len(doc['shifts']) == n
+        for i, e in enumerate(doc['shifts']):
+            assert e['h_shift'] == [i, -100 - i] and e['v_shift'] == [-200 - i, i]
