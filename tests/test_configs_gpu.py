@@ -147,3 +147,31 @@ def test_config3_planes_from_files_to_store_at_full_size(tmp_path):
     for lv, lvl in enumerate(O.pyramid_nearest(want, 6)):
         if lv:
             np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, str(lv))), lvl)
+
+
+def test_stitch_region_large_planes_distinct_gains_per_channel(tmp_path):
+    """planes big enough that a fusion launch is still running when the next one's pointer
+    table is uploaded.  2 channels x 2 z of a 4x4 grid of 2048^2 tiles, a different gain image per channel,
+    tiny ingest batches (one plane each) so launches follow one another back to back through stitch_region;
+    every plane must come out divided by ITS channel's gains."""
+    import torch
+    dev = torch.device('cuda:0')
+    spec = synth.GridSpec(rows=4, cols=4, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, seed=4100, nz=2,
+                          channels=synth.DEFAULT_CHANNELS[:2])
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition_device(spec, root, dev)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, apply_flatfield=True), normalization='phase')
+    st.batch_bytes_limit = 16 * 2048 * 2048 * 2          # one plane per batch -> four launches in a row
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    base = synth.synthetic_flatfield(2048, 2048, np.float32)
+    flats = {0: base, 1: (base[::-1, ::-1] * np.float32(1.75)).copy()}
+    st.flatfields = flats
+    st.calculate_shifts(0, 'R0')
+    assert (st.h_shift, st.v_shift) == ((3, -244), (-244, -2))
+    got = st.stitch_region(0, 'R0')
+    acq = O.parse_acquisition(root, read_image)
+    want = O.stitch_region(acq, 0, 'R0', read_image, True, {'h_shift': st.h_shift, 'v_shift': st.v_shift}, flats, True)
+    assert got.shape == want.shape == (1, 2, 2, want.shape[3], want.shape[4])
+    for c in range(2):
+        for z in range(2):
+            np.testing.assert_array_equal(got[0, c, z], want[0, c, z], err_msg=f'channel {c} z {z}')

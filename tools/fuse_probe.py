@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--nflats', type=int, default=1, help='distinct flatfields, dealt to planes in blocks (channels)')
     ap.add_argument('--drift', type=int, nargs=2, default=[3, -2])
+    ap.add_argument('--rcp', action='store_true', help='gains as [2, H, W]: gains, then correctly rounded reciprocals (-DSQ_RCP_TABLE=1 builds)')
+    ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g, T = a.grid, a.tile
@@ -44,8 +46,11 @@ def main():
     canvas = torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)
     flats = None
     if a.flat != 'none':
-        ff = torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)).to(dev)
-        ffs = [ff.clone() for _ in range(a.nflats)]
+        g = synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)
+        if a.rcp:
+            ffs = [torch.from_numpy(np.stack([g, (g.dtype.type(1) / g).astype(g.dtype)])).to(dev)[0] for _ in range(a.nflats)]
+        else:
+            ffs = [torch.from_numpy(g).to(dev) for _ in range(a.nflats)]
         flats = [ffs[p * a.nflats // a.planes] for p in range(a.planes)]
     for _ in range(2):
         native.fuse_planes(plan, tiles, canvas, flats)
@@ -61,6 +66,10 @@ def main():
     ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
     vox = a.planes * hc * wc
     alg = a.planes * (plan.covered_voxels * 4 + (hc * wc - plan.covered_voxels) * 2)
+    if a.check:
+        from oracle import stitch_oracle as O
+        want = O.fuse_plane_overwrite(list(tiles[0].cpu().numpy()), rects, hc, wc, None if flats is None else g)
+        print('plane 0 mismatched voxels vs oracle:', int(np.count_nonzero(canvas[0].cpu().numpy() != want)))
     print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
           f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
 
