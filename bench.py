@@ -5,21 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (default ``cfg3`` = BASELINE.json configs[2], the largest single-GPU configuration;
-the metric's own 32x32x4cx50z configuration is 1.6 TiB of tiles and does not fit one GPU):
-a 16x16 grid of 2048x2048 uint16 tiles, 4 channels x 10 z, ``-r -ff`` (registration +
-float32 flatfield), synthetic tiles generated on the device and resident in HBM before the
-timed region.  With N GPUs every rank stitches one such region (weak scaling: regions/wells
-are independent, like planes); the only collective is the all-gather of the shift table.
+N = 1 (default workload ``cfg3`` = BASELINE.json configs[2], the largest configuration that is resident on one
+GPU): a 16x16 grid of 2048x2048 uint16 tiles, 4 channels x 10 z, ``-r -ff`` (registration + float32 flatfield),
+synthetic tiles generated on the device and resident in HBM before the timed region.  One step = per-tile
+min/max + centre-pair phase cross-correlation on the registration plane (device), host integer geometry + span
+plan, then ONE fusion launch over all 40 planes.
 
-One step = one pass of the hot path over the resident region(s): per-tile min/max + centre-pair
-phase cross-correlation on the registration plane (device), all-gather of the shift rows
-(N > 1), host integer geometry + span plan, then ONE fusion launch over all 40 planes.
+N > 1 (default workload ``cfg4`` = BASELINE.json configs[3], the configuration the metric is quoted on): the
+32x32 grid of 2048x2048 tiles, 4 channels x 50 z = 200 (c, z) planes = 1.6 TiB of tiles, ``-r -ff``.  STRONG
+scaling: the 200 planes are dealt block-cyclically over the N ranks (plane p -> rank p % N), no image data is
+exchanged; rank 0 registers the centre pairs and the shift row is all-gathered over RCCL once per step.  A rank
+walks its planes in HBM-resident batches (tiles + canvases of a batch fill the card); a batch's tiles are
+synthesised on the device BEFORE that batch's timed segment starts (inputs resident when timing starts, as the
+contract says; the generator is not part of the hot path).  One step = the whole 200-plane job; the timed
+seconds of a rank are registration + all-gather + plan + the fusion launches of all its batches, and the job
+time is the MAX over ranks.  ``--workload cfg4`` runs the same job on one GPU.
 
 Printed JSON (rank 0, one line): whole-job Mvoxel/s, plus
-  roofline     fusion kernel, algorithmic bytes / HIP-event launch time vs 8 TB/s HBM peak
-  cpu_baseline the numpy oracle (oracle/stitch_oracle.py) timed on this box's host on one
-               (c, z) plane of the same workload (N = 1, rank 0 only)
+  roofline     fusion kernel, algorithmic bytes / HIP-event launch time vs 8 TB/s HBM peak (rank 0's launches)
+  cpu_baseline the numpy oracle (oracle/stitch_oracle.py) timed on this box's host on a bounded sample of
+               the same workload (N = 1, rank 0 only), and the genuine reference's timing from the authoring
+               container for the record
 """
 import argparse
 import json
@@ -41,9 +47,17 @@ WORKLOADS = {
     'cfg4shard': dict(grid=32, channels=4, nz=2, flat=True,
                       desc='32x32 grid of 2048x2048 uint16 tiles, 4 ch, 2 of 50 z resident per GPU, -r -ff '
                            '(BASELINE configs[3] shard)'),
+    'cfg4': dict(grid=32, channels=4, nz=50, flat=True, job=True,
+                 desc='32x32 grid of 2048x2048 uint16 tiles, 4 ch, 50 z, -r -ff, 200 planes dealt over the GPUs '
+                      '(BASELINE configs[3], the configuration the metric is quoted on)'),
 }
 TILE, OVERLAP, DRIFT = 2048, 244, (3, -2)
 HBM_PEAK_GBS = 8000.0
+# the genuine reference (unmodified /root/reference/stitcher.py, scikit-image 0.18.3, dask's threaded scheduler)
+# cannot travel to the GPU box; its timing is from the authoring container (tools/time_reference.py)
+REFERENCE_TIMING = {'value': 18.6, 'unit': 'Mvoxel/s', 'cores': 8, 'kind': 'reference',
+                    'sample': 'one (c,z) plane of config 3 (16x16 x 2048^2, -r -ff): stitch_region(...).compute() 57.2 s',
+                    'where': 'authoring container, 8 host cores (not this box); tools/time_reference.py'}
 
 
 def main():
@@ -51,16 +65,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='cfg3')
-    ap.add_argument('--planes', type=int, default=0, help='override the number of resident (c,z) planes')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default=None,
+                    help='default: cfg3 on one GPU, cfg4 (the headline job, strong scaling) on several')
+    ap.add_argument('--planes', type=int, default=0, help='override the number of (c,z) planes (resident planes / job size)')
+    ap.add_argument('--batch', type=int, default=0, help='cfg4: planes per resident batch (default: what fits, at most 12)')
+    ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sha-out', default=None,
+                    help='cfg4: write {plane: SHA-256 of its fused canvas} of the last step to this JSON file (one file per '
+                         'rank, ".rankR" appended); slow, for the N-rank == 1-rank check, not for timing')
     ap.add_argument('--traffic-bytes', type=float, default=None,
-                    help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else null)')
+                    help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else the committed measurement)')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from image_stitcher_amd import native, placement, registration, sharding, synth
+    from image_stitcher_amd import sharding
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -80,15 +100,82 @@ def main():
         else:
             dist.init_process_group(backend)
     coll_dev = dev if backend == 'nccl' else None
+    name = args.workload or ('cfg3' if world == 1 else 'cfg4')
+    wl = dict(WORKLOADS[name], name=name)
+    ctx = dict(args=args, rank=rank, world=world, dev=dev, coll_dev=coll_dev, wl=wl, backend=backend)
+    if wl.get('job'):
+        out = run_job(ctx)
+    else:
+        if world > 1 and not args.weak:
+            raise SystemExit(f"workload {name} on {world} GPUs is a weak-scaling run (one region per rank): pass --weak, "
+                             "or use the default workload (cfg4, strong scaling)")
+        out = run_region(ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
-    wl = WORKLOADS[args.workload]
-    g, C, Z = wl['grid'], wl['channels'], wl['nz']
-    n_planes = C * Z
+
+# ------------------------------------------------------------------------------------------------------------
+# shared pieces
+# ------------------------------------------------------------------------------------------------------------
+def grid_setup(g, rank_seed):
+    from image_stitcher_amd import placement, synth
     spec = synth.GridSpec(rows=g, cols=g, tile_h=TILE, tile_w=TILE, ov_y=OVERLAP, ov_x=OVERLAP,
-                          jy=DRIFT[0], jx=DRIFT[1], channels=synth.DEFAULT_CHANNELS[:C], nz=Z,
-                          seed=1000 * 3 + rank * 100)
+                          jy=DRIFT[0], jx=DRIFT[1], channels=synth.DEFAULT_CHANNELS[:4], nz=50, seed=rank_seed)
     truth = placement.Shifts((DRIFT[0], -OVERLAP), (-OVERLAP, DRIFT[1]))
     wc, hc = placement.canvas_size(g, g, TILE, TILE, use_registration=True, shifts=truth)
+    xs = [spec.stage_mm(0, c)[0] for c in range(g)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(g)]
+    # write order inside a plane = sorted file names of the fov numbers (stitcher.py:168)
+    order = placement.filename_order([spec.fov_index(r, c) for r in range(g) for c in range(g)])
+    order_rc = [divmod(i, g) for i in order]
+    return spec, truth, wc, hc, xs, ys, order, order_rc
+
+
+def plane_desc(spec, g, c, z):
+    """Generator descriptors of the g x g tiles of plane (c, z), storage (row-major) order."""
+    from image_stitcher_amd import native
+    desc = np.zeros(g * g, dtype=native.SYNTH_DTYPE)
+    scene = spec.scene_seed(0, 0, z, c) % 2 ** 64
+    for r in range(g):
+        for col in range(g):
+            oy, ox = spec.origin(r, col)
+            desc[r * g + col] = (scene, spec.noise_seed(0, 0, z, c, spec.fov_index(r, col)) % 2 ** 64, oy, ox)
+    return desc
+
+
+def algorithmic_bytes(n_planes, covered, hc, wc, flat):
+    # SURVEY 8(d): 4 B per covered voxel (2 B read + 2 B write), 2 B per uncovered voxel (zero write),
+    # + the float32 flatfield once per plane
+    return n_planes * (covered * 4 + (hc * wc - covered) * 2 + (TILE * TILE * 4 if flat else 0))
+
+
+def committed_traffic(workload, n_planes):
+    """PMC counters need their own rocprofv3 passes (the guide's HBM section: separate --pmc runs); the bench line
+    carries the last committed measurement of this exact launch, and says so."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')) as fh:
+            pm = json.load(fh)
+        if pm.get('workload') == workload and pm.get('planes') == n_planes:
+            return pm['traffic_bytes_per_launch'], 'profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of ' \
+                'this launch on another box; not measured in this run)'
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, 'not measured (no committed PMC pass for this workload / plane count)'
+
+
+# ------------------------------------------------------------------------------------------------------------
+# region workloads (cfg2 / cfg3 / cfg4shard): everything resident, one launch per step
+# ------------------------------------------------------------------------------------------------------------
+def run_region(ctx):
+    import torch
+    import torch.distributed as dist
+    from image_stitcher_amd import native, placement, registration, sharding, synth
+    args, rank, world, dev, coll_dev, wl = (ctx[k] for k in ('args', 'rank', 'world', 'dev', 'coll_dev', 'wl'))
+    g, C, Z = wl['grid'], wl['channels'], wl['nz']
+    n_planes = C * Z
+    spec, truth, wc, hc, xs, ys, order, order_rc = grid_setup(g, 1000 * 3 + rank * 100)
     plane_in = g * g * TILE * TILE * 2
     plane_out = hc * wc * 2
     free, total = torch.cuda.mem_get_info(dev)
@@ -107,25 +194,15 @@ def main():
     tiles = torch.empty((n_planes, g * g, TILE, TILE), dtype=torch.uint16, device=dev)
     for p in range(n_planes):
         c, z = divmod(p, Z_eff)
-        desc = np.zeros(g * g, dtype=native.SYNTH_DTYPE)
-        for r in range(g):
-            for col in range(g):
-                oy, ox = spec.origin(r, col)
-                desc[r * g + col] = (spec.scene_seed(0, 0, z, c) % 2 ** 64,
-                                     spec.noise_seed(0, 0, z, c, spec.fov_index(r, col)) % 2 ** 64, oy, ox)
-        native.synth_tiles(desc, TILE, TILE, spec.noise, 'uint16', dev, out=tiles[p])
+        native.synth_tiles(plane_desc(spec, g, c, z), TILE, TILE, spec.noise, 'uint16', dev, out=tiles[p])
     flat_list = None
     if wl['flat']:
         ffs = [torch.from_numpy(synth.synthetic_flatfield(TILE, TILE, np.float32) * np.float32(1 + 0.03125 * c)).to(dev)
                for c in range(C_eff)]
         flat_list = [ffs[p // Z_eff] for p in range(n_planes)]
     flat_ptrs = native.pointer_table(flat_list, dev) if flat_list else None
-    canvas = torch.empty((n_planes, hc, wc), dtype=torch.uint16, device=dev)
-    xs = [spec.stage_mm(0, c)[0] for c in range(g)]
-    ys = [spec.stage_mm(r, 0)[1] for r in range(g)]
-    # write order inside a plane = sorted file names of the fov numbers (stitcher.py:168)
-    order = placement.filename_order([spec.fov_index(r, c) for r in range(g) for c in range(g)])
-    order_rc = [divmod(i, g) for i in order]
+    # dense rows like the reference's array; every plane starts on a 128-byte line (native.empty_canvas)
+    canvas = native.empty_canvas(n_planes, hc, wc, torch.uint16, dev)
     tile_order = torch.tensor(order, dtype=torch.int64)
     # tile pointer table in write order (plane-major), so rect i <-> pointer i
     esz = TILE * TILE * 2
@@ -138,7 +215,6 @@ def main():
     fuse_events = []
     state = {}
     gathers = []
-
     lap = {}
 
     def tick(name, t_prev):
@@ -169,7 +245,8 @@ def main():
         gathers.append((row, sharding.all_gather_shift_table_async(row[None], device=coll_dev)))
         mine = sharding.row_to_shifts(row)
         t = tick('allgather', t)
-        # host integer geometry + span plan (rebuilt every step: it depends on the shifts)
+        # host integer geometry + span plan (rebuilt every step: every region is registered on its own tiles and
+        # its plan follows from ITS shifts -- no cache across regions here; cfg4 below is one region per job)
         rects = placement.grid_rects(g, g, TILE, TILE, mine, order=order_rc)
         w_px, h_px = placement.canvas_size(g, g, TILE, TILE, use_registration=True, shifts=mine)
         if (w_px, h_px) != (wc, hc):
@@ -226,22 +303,10 @@ def main():
     voxels_per_step = world * n_planes * hc * wc
     value = voxels_per_step * args.steps / elapsed / 1e6
     fuse_ms = float(np.mean([a.elapsed_time(b) for a, b in fuse_events]))
-    covered = plan.covered_voxels
-    # 4 B per covered voxel (2 B read + 2 B write), 2 B per uncovered voxel (zero write),
-    # + the float32 flatfield once per plane
-    alg_bytes = n_planes * (covered * 4 + (hc * wc - covered) * 2 + (TILE * TILE * 4 if wl['flat'] else 0))
+    alg_bytes = algorithmic_bytes(n_planes, plan.covered_voxels, hc, wc, wl['flat'])
     achieved = alg_bytes / (fuse_ms * 1e-3) / 1e9
-    traffic = args.traffic_bytes
-    if traffic is None:
-        # PMC counters need their own rocprofv3 passes; the last committed measurement of this exact
-        # launch (same workload, same plane count) is reported, else null
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')) as fh:
-                pm = json.load(fh)
-            if pm.get('workload') == args.workload and pm.get('planes') == n_planes:
-                traffic = pm['traffic_bytes_per_launch']
-        except (OSError, ValueError, KeyError):
-            traffic = None
+    traffic, traffic_source = (args.traffic_bytes, 'rocprofv3 --pmc passes of this command (--traffic-bytes)') \
+        if args.traffic_bytes is not None else committed_traffic(wl['name'], n_planes)
 
     out = {
         'metric': 'stitched Mvoxels/s', 'value': round(value, 1), 'unit': 'Mvoxel/s',
@@ -254,9 +319,10 @@ def main():
                    'shifts': {'h': list(state['shifts'].h_shift), 'v': list(state['shifts'].v_shift)},
                    'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes; the next '
                            "region's registration is enqueued ahead of the fusion launch (regions are independent)"},
-        'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_kernel<u16,f32 flat>' if wl['flat'] else 'fuse_overwrite_kernel<u16>',
+        'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_zg_kernel (u16, f32 gains, plane groups)' if wl['flat'] and n_planes > 1
+                     else ('fuse_overwrite_kernel<u16,f32 flat>' if wl['flat'] else 'fuse_overwrite_kernel<u16>'),
                      'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                      'algorithmic_bytes_per_launch': int(alg_bytes), 'launch_ms': round(fuse_ms, 4)},
     }
 
@@ -264,24 +330,38 @@ def main():
         n = args.steps + args.warmup
         print('[bench] host ms per step: ' + ', '.join(f'{k} {v / n * 1e3:.2f}' for k, v in lap.items()), file=sys.stderr)
     # accuracy side of the metric (BASELINE.json: shift RMSE <= 0.5 px, fused max-rel-err <= 1e-5)
-    sh = state['shifts']
+    out['parity'] = shift_parity(state['shifts'], truth)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas)
+        out['cpu_baseline_reference'] = REFERENCE_TIMING
+        out['parity'].update(check)
+    return out
+
+
+def shift_parity(sh, truth):
     err = np.array([sh.h_shift[0] - truth.h_shift[0], sh.h_shift[1] - truth.h_shift[1],
                     sh.v_shift[0] - truth.v_shift[0], sh.v_shift[1] - truth.v_shift[1]], dtype=np.float64)
-    out['parity'] = {'shift_rmse_px': float(np.sqrt((err ** 2).mean())), 'shift_reference': 'planted drift'}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, canvas)
-        out['parity'].update(check)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    return {'shift_rmse_px': float(np.sqrt((err ** 2).mean())), 'shift_reference': 'planted drift'}
 
 
-def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, truth, canvas, max_planes=16):
+def oracle_rects(O, g, xs, ys, h, v, order, spec, hc, wc):
+    """The write-ordered rectangles from the ORACLE's own restatement of the reference's placement and crop
+    (oracle.tile_rect, stitcher.py:656-679 / :570-587) -- nothing of the product's geometry code."""
+    rects = []
+    for i in order:
+        r, c = divmod(i, g)
+        info = {'x': xs[c], 'y': ys[r]}
+        x_px, y_px, top, bottom, left, right = O.tile_rect(info, list(xs), list(ys), TILE, TILE, spec.pixel_size_um, True,
+                                                           tuple(h), tuple(v), None, 0, wc, hc)
+        rects.append((top, left, TILE - top - bottom, TILE - left - right, y_px + top, x_px + left))
+    return np.array(rects, dtype=np.int64)
+
+
+def cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas, max_planes=16):
     """The oracle (a numpy port of the reference path) on a bounded sample of the same workload:
     registration of the two centre pairs once (stitcher.py:1244-1246), then overwrite fusion of
-    up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work."""
-    from image_stitcher_amd import placement
+    up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work.  Geometry, shifts and voxels all come
+    from oracle code; the GPU canvas is compared with the result voxel by voxel."""
     from oracle import stitch_oracle as O
     n = min(max_planes, tiles.shape[0])
     host = tiles[:n].cpu().numpy()
@@ -292,7 +372,9 @@ def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, tru
     h = O.calculate_horizontal_shift(host[0, ri * g + ci], host[0, ri * g + ci + 1], mx, np.uint16, 'phase')
     v = O.calculate_vertical_shift(host[0, ri * g + ci], host[0, (ri + 1) * g + ci], my, np.uint16, 'phase')
     assert (tuple(h), tuple(v)) == (truth.h_shift, truth.v_shift)
-    rects = placement.grid_rects(g, g, TILE, TILE, placement.Shifts(tuple(h), tuple(v)), order=order_rc)
+    ow, oh, _ = O.output_dimensions(list(xs), list(ys), TILE, TILE, spec.pixel_size_um, True, tuple(h), tuple(v), None, 1)
+    assert (oh, ow) == (hc, wc), f"oracle canvas {oh}x{ow} != device canvas {hc}x{wc}"
+    rects = oracle_rects(O, g, xs, ys, h, v, order, spec, hc, wc)
     voxels = 0
     dt_check = 0.0
     mismatched = 0
@@ -308,7 +390,198 @@ def cpu_baseline(tiles, flat_list, order, order_rc, spec, xs, ys, g, hc, wc, tru
             'sample': f'{n} (c,z) planes of the workload ({g}x{g} tiles -> {hc}x{wc} canvas each): registration of '
                       f'the 2 centre pairs once + fusion, numpy oracle, {dt:.1f} s, 1 of {os.cpu_count()} host cores used'}
     check = {'fused_max_rel_err': 0.0 if mismatched == 0 else None, 'fused_mismatched_voxels': mismatched,
-             'fused_checked': f'{n} of the timed launch\'s canvas planes compared voxel by voxel with the oracle'}
+             'fused_checked': f'{n} of the timed launch\'s canvas planes compared voxel by voxel with the oracle '
+                              '(shifts, canvas size and rectangles from the oracle\'s own geometry)'}
+    return base, check
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the headline job (cfg4): 200 planes of a 32x32 grid dealt over the ranks, walked in resident batches
+# ------------------------------------------------------------------------------------------------------------
+def run_job(ctx):
+    import torch
+    import torch.distributed as dist
+    from image_stitcher_amd import native, placement, registration, sharding, synth
+    args, rank, world, dev, coll_dev, wl = (ctx[k] for k in ('args', 'rank', 'world', 'dev', 'coll_dev', 'wl'))
+    g, C, Z = wl['grid'], wl['channels'], wl['nz']
+    total_planes = args.planes or C * Z
+    spec, truth, wc, hc, xs, ys, order, order_rc = grid_setup(g, 1000 * 4)     # every rank: the SAME acquisition
+    mine = sharding.block_cyclic(total_planes, rank, world)                    # plane p = c * Z + z  ->  rank p % world
+    plane_in, plane_out = g * g * TILE * TILE * 2, hc * wc * 2
+    free, _ = torch.cuda.mem_get_info(dev)
+    fit = int((free - (8 << 30)) // (plane_in + plane_out))
+    if fit < 1:
+        raise SystemExit(f"[bench] not even one plane of the 32x32 grid fits in {free / 2**30:.0f} GiB of free HBM")
+    cap = args.batch or min(fit, 12)
+    n_batches = max(1, -(-len(mine) // cap))
+    bsz = -(-len(mine) // n_batches) if mine else 0          # balanced batches: 25 planes -> 9, 8, 8
+    batches = [mine[i:i + bsz] for i in range(0, len(mine), bsz)] if bsz else []
+    bmax = max((len(b) for b in batches), default=1)
+
+    tiles = torch.empty((bmax, g * g, TILE, TILE), dtype=torch.uint16, device=dev)
+    canvas = native.empty_canvas(bmax, hc, wc, torch.uint16, dev)
+    ffs = [torch.from_numpy(synth.synthetic_flatfield(TILE, TILE, np.float32) * np.float32(1 + 0.03125 * c)).to(dev)
+           for c in range(C)]
+    descs = {p: plane_desc(spec, g, p // Z, p % Z) for p in mine}
+    tile_order = torch.tensor(order, dtype=torch.int64)
+    esz = TILE * TILE * 2
+    ptrs_all = (tiles.data_ptr() + (torch.arange(bmax, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
+    ptrs_all = ptrs_all.reshape(-1).to(dev)
+    flat_tables = [native.pointer_table([ffs[p // Z] for p in b], dev) for b in batches]
+    # rank 0 holds the three tiles the reference registers on (centre, right, below; channel 0, z 0: stitcher.py:455-485)
+    ci = ri = (g - 1) // 2
+    reg_cells = [(ri, ci), (ri, ci + 1), (ri + 1, ci)]
+    reg_tiles = None
+    if rank == 0:
+        d0 = plane_desc(spec, g, 0, 0)
+        reg_tiles = native.synth_tiles(d0[[r * g + c for r, c in reg_cells]], TILE, TILE, spec.noise, 'uint16', dev)
+    reg_index = {rc: i for i, rc in enumerate(reg_cells)}
+    torch.cuda.synchronize()
+
+    plans = {}
+    fuse_events, state, lap = [], {}, {}
+
+    def plan_for(shifts):
+        """Host geometry + span plan, kept across steps while the shifts do not change (the plan depends on
+        nothing else); one upload per plan."""
+        rects = placement.grid_rects(g, g, TILE, TILE, shifts, order=order_rc)
+        key = rects.tobytes()
+        if key not in plans:
+            w_px, h_px = placement.canvas_size(g, g, TILE, TILE, use_registration=True, shifts=shifts)
+            if (w_px, h_px) != (wc, hc):
+                raise RuntimeError(f"registration returned {shifts}, canvas {h_px}x{w_px} != planned {hc}x{wc}")
+            plans.clear()
+            plans[key] = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE)
+        return plans[key]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def job(record):
+        """One pass over the 200 planes.  Returns this rank's timed seconds."""
+        timed = 0.0
+        sync_all()
+        t0 = time.perf_counter()
+        row = sharding.shifts_to_row(None)
+        if rank == 0:    # the reference registers once, on the first region's centre tiles (stitcher.py:1244-1246)
+            sh = registration.register_grid_center(reg_tiles, g, g, xs, ys, spec.pixel_size_um, spec.pixel_binning,
+                                                   normalization='phase', tile_index=lambda r, c: reg_index[(r, c)])
+            row = sharding.shifts_to_row(sh)
+        shifts = sharding.first_valid(sharding.all_gather_shift_table(row[None], device=coll_dev))   # RCCL
+        plan = plan_for(shifts)
+        torch.cuda.synchronize()
+        timed += time.perf_counter() - t0
+        lap['register+allgather+plan'] = lap.get('register+allgather+plan', 0.0) + (time.perf_counter() - t0)
+        for bi, b in enumerate(batches):
+            for k, p in enumerate(b):      # this batch's tiles -> HBM (not timed: inputs are resident when timing starts)
+                native.synth_tiles(descs[p], TILE, TILE, spec.noise, 'uint16', dev, out=tiles[k])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            native.fuse_planes(plan, None, canvas[:len(b)], [ffs[p // Z] for p in b], tile_ptrs=ptrs_all[:len(b) * g * g],
+                               flat_ptrs=flat_tables[bi])
+            e1.record()
+            torch.cuda.synchronize()
+            timed += time.perf_counter() - t0
+            if record:
+                fuse_events.append((e0, e1, len(b)))
+            if args.sha_out and record == 'last':
+                import hashlib
+                for k, p in enumerate(b):
+                    state.setdefault('sha', {})[int(p)] = hashlib.sha256(canvas[k].cpu().numpy().tobytes()).hexdigest()
+        state['plan'], state['shifts'] = plan, shifts
+        return timed
+
+    for _ in range(args.warmup):
+        job(False)
+    seconds = 0.0
+    for k in range(args.steps):
+        seconds += job('last' if k + 1 == args.steps else True)
+    sync_all()
+    if args.sha_out:
+        with open(f'{args.sha_out}.rank{rank}', 'w') as fh:
+            json.dump(state.get('sha', {}), fh)
+    mine_s = seconds
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev or 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t.item())
+
+    plan, shifts = state['plan'], state['shifts']
+    assert tuple(shifts.h_shift) == truth.h_shift and tuple(shifts.v_shift) == truth.v_shift, \
+        f"registration did not recover the planted drift: {shifts}"
+    value = total_planes * hc * wc * args.steps / seconds / 1e6
+    ms = np.array([a.elapsed_time(b) for a, b, _ in fuse_events]) if fuse_events else np.zeros(1)
+    npl = np.array([n for _, _, n in fuse_events]) if fuse_events else np.ones(1)
+    alg = algorithmic_bytes(1, plan.covered_voxels, hc, wc, True)
+    achieved = alg * npl.sum() / (ms.sum() * 1e-3) / 1e9 if ms.sum() > 0 else 0.0
+    fracs = [achieved / HBM_PEAK_GBS]
+    if world > 1:      # every rank's fraction, for the record
+        t = torch.tensor([achieved / HBM_PEAK_GBS], dtype=torch.float64, device=coll_dev or 'cpu')
+        allf = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allf, t)
+        fracs = [float(x.item()) for x in allf]
+    out = {
+        'metric': 'stitched Mvoxels/s', 'value': round(value, 1), 'unit': 'Mvoxel/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(seconds / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
+        'config': {'workload': wl['desc'], 'planes_total': total_planes, 'planes_per_gpu': len(mine),
+                   'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g,
+                   'parallelism': f'planes block-cyclic over {world} GPUs (plane p -> rank p % {world}), rank 0 registers, '
+                                  f'shift row all-gathered over {"RCCL" if ctx["backend"] == "nccl" else ctx["backend"]}, no image data exchanged',
+                   'shifts': {'h': list(shifts.h_shift), 'v': list(shifts.v_shift)},
+                   'step': 'the whole job: centre-pair PCC on rank 0 + all-gather + span plan (kept while the shifts stay), then per '
+                           'resident batch one fusion launch; a batch\'s tiles are synthesised on the device before its timed '
+                           'segment (inputs resident when timing starts); timed = MAX over ranks of the summed segments'},
+        'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_zg_kernel (u16, f32 gains, plane groups)', 'achieved': round(achieved, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                     'traffic_source': 'not measured (no PMC pass for this workload)',
+                     'algorithmic_bytes_per_launch': int(alg * npl.mean()), 'launch_ms': round(float(ms.mean()), 4),
+                     'frac_per_rank': [round(f, 4) for f in fracs], 'of_rank': 0},
+        'parity': shift_parity(shifts, truth),
+    }
+    if rank == 0 and os.environ.get('SQ_BENCH_BREAKDOWN'):
+        n = args.steps + args.warmup
+        print(f'[bench] rank 0 timed {mine_s / args.steps * 1e3:.2f} ms/job; host ms per job: ' +
+              ', '.join(f'{k} {v / n * 1e3:.2f}' for k, v in lap.items()), file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the last batch is still resident: the oracle on a bounded sample of it (2 planes of the 32x32 grid)
+        b = batches[-1]
+        flat_list = [ffs[p // Z] for p in b]
+        base, check = cpu_baseline_fusion_only(tiles[:len(b)], flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas[:len(b)])
+        out['cpu_baseline'], out['cpu_baseline_reference'] = base, REFERENCE_TIMING
+        out['parity'].update(check)
+    return out
+
+
+def cpu_baseline_fusion_only(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas, max_planes=2):
+    """cfg4's resident batch does not hold the registration plane: the oracle's fusion (with the planted shifts the
+    device registration was checked against) on a bounded sample, compared with the GPU canvas."""
+    from oracle import stitch_oracle as O
+    n = min(max_planes, tiles.shape[0])
+    host = tiles[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    rects = oracle_rects(O, g, xs, ys, truth.h_shift, truth.v_shift, order, spec, hc, wc)
+    voxels = mismatched = 0
+    dt_check = 0.0
+    for p in range(n):
+        plane = O.fuse_plane_overwrite([host[p, i] for i in order], rects, hc, wc, flat_list[p].cpu().numpy())
+        voxels += plane.size
+        tc = time.perf_counter()
+        mismatched += int(np.count_nonzero(canvas[p].cpu().numpy() != plane))
+        dt_check += time.perf_counter() - tc
+        del plane
+    dt = time.perf_counter() - t0 - dt_check
+    base = {'value': round(voxels / dt / 1e6, 1), 'unit': 'Mvoxel/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} (c,z) planes of the workload ({g}x{g} tiles -> {hc}x{wc} canvas each): fusion only, numpy oracle, '
+                      f'{dt:.1f} s, 1 of {os.cpu_count()} host cores used'}
+    check = {'fused_max_rel_err': 0.0 if mismatched == 0 else None, 'fused_mismatched_voxels': mismatched,
+             'fused_checked': f'{n} planes of the last resident batch compared voxel by voxel with the oracle'}
     return base, check
 
 

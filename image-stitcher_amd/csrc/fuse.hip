@@ -92,7 +92,22 @@ struct FuseParams {
     int32_t lane_items;           // list positions [0, 8 * lane_items) of a plane are lane-interleaved
     int32_t n_planes;
     int32_t chunk;                // consecutive lane positions a workgroup takes per atomic, 1..QUEUE_CHUNK
+    const struct PlaneGroup *groups;   // plane groups of the float32-gain kernel (build_groups_kernel), else NULL
+    const uint32_t *n_groups;          // how many there are (device side: the host never learns it)
 };
+// Planes that are divided by the SAME gain image (the z planes of a channel) and whose canvas rows sit at the same
+// phase inside a 128-byte line are carried through an item together: the gains and their reciprocals are loaded /
+// computed once per group instead of once per plane.  32 bytes.
+#ifndef SQ_ZB
+#define SQ_ZB 5
+#endif
+constexpr int ZB = SQ_ZB;            // most planes in a group
+static_assert(ZB >= 1 && ZB <= 7, "a PlaneGroup holds at most 7 planes");
+struct PlaneGroup {
+    int32_t n;          // 1..ZB
+    int32_t plane[7];
+};
+static_assert(sizeof(PlaneGroup) == 32, "PlaneGroup layout");
 constexpr int QUEUE_STRIDE = 32;   // uint32 words between the counters
 #ifndef SQ_QUEUE_CHUNK
 #define SQ_QUEUE_CHUNK 8
@@ -540,17 +555,18 @@ __device__ __forceinline__ const T *sgpr(const T *p) {
 // workgroup is handed, all threads of the workgroup together, arguments in scalar registers.
 // aux = pre(plane, item) is evaluated by the thread that loads the descriptor (the overwrite kernel
 // fetches the tile pointer there, so that eight of them are in flight at once).
-template <typename Pre, typename Body>
-__device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const int64_t n_items, Pre pre, Body body) {
+template <typename Aux, typename Pre, typename Body>
+__device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const int64_t n_items, const uint32_t n_units, Pre pre,
+                                                     Body body) {
     __shared__ int s_q[2];
     __shared__ uint32_t s_c[2];
     __shared__ Item s_item[QUEUE_CHUNK];          // the chunk's descriptors, loaded by QUEUE_CHUNK threads at once
     __shared__ int s_plane[QUEUE_CHUNK];
-    __shared__ const void *s_aux[QUEUE_CHUNK];
+    __shared__ Aux s_aux[QUEUE_CHUNK];
     const int home = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);   // HW_REG_XCC_ID[3:0]
     // queue q holds n_planes * per_plane(q) positions; 32-bit arithmetic (the host checks the sizes)
     auto per_plane_of = [&](int q) { return (uint32_t)(q < 8 ? (int64_t)P.lane_items : n_items - 8 * (int64_t)P.lane_items); };
-    auto total_of = [&](int q) { return (uint32_t)P.n_planes * per_plane_of(q); };
+    auto total_of = [&](int q) { return n_units * per_plane_of(q); };
     int given_up = 0;   // thread 0: queues found empty so far (own lane first, then the others, then the rest)
     auto queue_of = [&](int k) { return k < 8 ? ((home + k) & 7) : 8; };
     auto settle = [&](uint32_t c) -> Chunk {   // thread 0: make (given_up, c) a real chunk or move on
@@ -587,7 +603,7 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
             s_aux[threadIdx.x] = pre(plane, it);
         }
         __syncthreads();
-        for (int j = 0; j < count; ++j) body(sgpr(s_plane[j]), sgpr(s_item[j]), sgpr(s_aux[j]));
+        for (int j = 0; j < count; ++j) body(sgpr(s_plane[j]), sgpr(s_item[j]), s_aux[j]);
         if (threadIdx.x == 0) {
             const Chunk nxt = pull ? settle(pending) : Chunk{-1, 0u};
             s_q[(iter + 1) & 1] = nxt.q;
@@ -630,12 +646,234 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
         }
         return;
     }
-    for_each_queued_item(
-        P, n_items,
+    for_each_queued_item<const void *>(
+        P, n_items, (uint32_t)P.n_planes,
         [&](int plane, const Item &it) -> const void * { return it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr; },
-        [&](int plane, const Item &it, const void *tile) {
-            process_item<T, FLAT>(P, plane, it, static_cast<const T *>(tile), wave, lane);
+        [&](int plane, const Item &it, const void *const &tile) {
+            process_item<T, FLAT>(P, plane, it, sgpr(static_cast<const T *>(tile)), wave, lane);
         });
+}
+
+// ---------------------------------------------------------------------------------------------
+// overwrite mode, uint16 tiles, float32 gains: plane groups
+// ---------------------------------------------------------------------------------------------
+// The z planes of a channel share one gain image and one plan, so a workgroup carries up to ZB of them through
+// an item together: per 16-byte slot a lane loads its 8 gains ONCE, takes their reciprocals ONCE (v_rcp_f32 is
+// a quarter-rate instruction: it was 4 of the ~10 issue cycles per pixel), and then streams the ZB planes'
+// pixels through the same 5-instruction Markstein divide (div_u16_normal above: the arithmetic and therefore
+// every bit of the result are the per-plane kernel's).  Per pixel and plane that leaves convert, multiply, two
+// FMAs, convert and half a pack; the gain traffic from L2 and the gain registers shrink by the group size, so
+// the ZB independent pixel loads of a slot are in flight together at 4 VGPRs each.
+// Loads are unconditional (lanes outside the row read a clamped, valid address and only their store is masked):
+// no divergent branch sits between the loads of a slot and their use.
+// Groups are built on the device (build_groups_kernel: the gain pointers live in device memory); a plane whose
+// gains need the generic divide, or that shares its gain image with nobody, is a group of one and takes the
+// per-plane pipeline (process_item).
+struct UnitAux {
+    PlaneGroup g;
+    const void *tile[ZB];
+};
+
+__device__ __forceinline__ uint32_t quot_pair(uint32_t word, float g_lo, float g_hi, float r_lo, float r_hi) {
+    const float n0 = (float)(word & 0xFFFFu), n1 = (float)(word >> 16);
+    const float q0 = n0 * r_lo, q1 = n1 * r_hi;
+    const uint32_t a = cvt_u32_sat(fmaf(fmaf(-g_lo, q0, n0), r_lo, q0));
+    const uint32_t b = cvt_u32_sat(fmaf(fmaf(-g_hi, q1, n1), r_hi, q1));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
+                                                const int wave, const int lane) {
+    typedef uint16_t T;
+    constexpr int VEC = 8, LINE = 64;
+    constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
+    const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    T *cplane[ZB];
+    const T *tiles[ZB];
+#pragma unroll
+    for (int z = 0; z < ZB; ++z) {
+        const int zz = (FULL || z < gn) ? z : 0;
+        cplane[z] = static_cast<T *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
+        tiles[z] = sgpr(static_cast<const T *>(A.tile[zz]));
+    }
+    if (!it.nref) {   // uncovered canvas: zeros (da.zeros, stitcher.py:362)
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn)
+                for (int r = wave; r < rows; r += 4)
+                    row_zero<T>(cplane[z] + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
+        return;
+    }
+    const float *flat = static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+    for (int r = wave; r < rows; r += 4) {
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int64_t soff = (int64_t)(it.b + r) * P.tile_pitch + it.c;
+        const float *frow = flat + (int64_t)(it.b + r) * P.tile_w + it.c;
+        // the phase of the row inside a 128-byte line: the same for every plane of the group (build_groups_kernel)
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (LINE - 1));
+        const int v_first = (mis + VEC - 1) / VEC, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int ep = -1;   // this lane's edge pixel: lanes 0..7 the head, 8..15 the tail
+        if (lane < VEC) {
+            if (lane < head_end) ep = lane;
+        } else if (lane < 2 * VEC) {
+            if (tail_start + (lane - VEC) < n) ep = tail_start + (lane - VEC);
+        }
+        const int epc = max(ep, 0);
+        const float eg = ldg_s<float>(frow + epc);
+        T e[ZB];
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) e[z] = ldg_s<T>(tiles[z] + soff + epc);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            if (64 * k >= v_end || v_end <= v_first) break;   // wave-uniform: no whole vector (left) in this row
+            const int v = lane + 64 * k;
+            const bool act = v >= v_first && v < v_end;
+            const int p0 = v * VEC - mis;
+            const int p0c = min(max(p0, 0), n - VEC);          // v_end > v_first implies n >= VEC
+            const f32x4 g0 = ldg<F32x4U>(frow + p0c), g1 = ldg<F32x4U>(frow + p0c + 4);
+            u32x4 px[ZB];
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) px[z] = ldg<U32x4U>(tiles[z] + soff + p0c);
+            f32x4 r0, r1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                r0[c] = __builtin_amdgcn_rcpf(g0[c]);
+                r1[c] = __builtin_amdgcn_rcpf(g1[c]);
+            }
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    u32x4 o;
+                    o[0] = quot_pair(px[z][0], g0[0], g0[1], r0[0], r0[1]);
+                    o[1] = quot_pair(px[z][1], g0[2], g0[3], r0[2], r0[3]);
+                    o[2] = quot_pair(px[z][2], g1[0], g1[1], r1[0], r1[1]);
+                    o[3] = quot_pair(px[z][3], g1[2], g1[3], r1[2], r1[3]);
+                    if (act) stg_nt(cplane[z] + doff + p0, o);
+                }
+        }
+        const float er = __builtin_amdgcn_rcpf(eg);
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                const float nf = (float)e[z];
+                const float q = nf * er;
+                const uint32_t kq = min(cvt_u32_sat(fmaf(fmaf(-eg, q, nf), er, q)), 65535u);
+                if (ep >= 0) stg_s<T>(cplane[z] + doff + ep, (T)kq);
+            }
+    }
+}
+
+#ifndef SQ_WAVES_ZG
+#define SQ_WAVES_ZG 1
+#endif
+template <bool DYN>
+__global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(const FuseParams P, const int64_t n_items) {
+    typedef uint16_t T;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_groups = *P.n_groups;
+    auto pre = [&](int unit, const Item &it) -> UnitAux {
+        UnitAux A;
+        A.g = P.groups[unit];
+#pragma unroll
+        for (int z = 0; z < ZB; ++z) A.tile[z] = (it.nref && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], it.a) : nullptr;
+        return A;
+    };
+    auto body = [&](int, const Item &it, const UnitAux &A) {
+        const int gn = sgpr(A.g.n);
+        if (gn == 1) {
+            process_item<T, 1>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
+        } else if (gn == ZB) {
+            process_item_zg<true>(P, A, gn, it, wave, lane);
+        } else {
+            process_item_zg<false>(P, A, gn, it, wave, lane);
+        }
+    };
+    if (DYN) {
+        for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);
+    } else {
+        __shared__ Item s_it;
+        __shared__ UnitAux s_A;
+        const int64_t n_work = (int64_t)n_groups * n_items;
+        for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int unit = (int)(work / n_items);
+                s_it = P.items[work - unit * n_items];
+                s_A = pre(unit, s_it);
+            }
+            __syncthreads();
+            body(0, sgpr(s_it), s_A);
+        }
+    }
+}
+
+// One block: deal the planes into groups of <= zb that share a gain image (and a fast gain class, and the phase
+// of their canvas inside a 128-byte line).  Planes are few (C x Z of a region); more than CAP of them, or zb = 1,
+// and every plane is its own group.
+__global__ __launch_bounds__(256) void build_groups_kernel(const void *const *flat_ptrs, const uint32_t *cls, int n_planes,
+                                                          int64_t plane_stride_bytes, int zb, uint32_t *n_groups,
+                                                          PlaneGroup *groups) {
+    constexpr int CAP = 1024;
+    __shared__ uint64_t key[CAP];
+    __shared__ int first[CAP], open_group[CAP];
+    __shared__ PlaneGroup out[CAP];
+    const int tid = threadIdx.x;
+    if (n_planes > CAP || zb <= 1) {
+        for (int p = tid; p < n_planes; p += 256) {
+            PlaneGroup g{};
+            g.n = 1;
+            g.plane[0] = p;
+            groups[p] = g;
+        }
+        if (tid == 0) *n_groups = (uint32_t)n_planes;
+        return;
+    }
+    for (int p = tid; p < n_planes; p += 256) {
+        const void *f = flat_ptrs ? flat_ptrs[p] : nullptr;
+        const bool ok = f && cls[p] == 0;
+        // 0 = "groups with nobody"; else the gain pointer (< 2^56) and the canvas plane's phase in a line
+        key[p] = ok ? ((reinterpret_cast<uint64_t>(f) << 7) | (uint64_t)(((int64_t)p * plane_stride_bytes) & 127) | (1ull << 63)) : 0;
+        open_group[p] = -1;
+    }
+    __syncthreads();
+    for (int p = tid; p < n_planes; p += 256) {
+        int f = p;
+        if (key[p])
+            for (int q = 0; q < p; ++q)
+                if (key[q] == key[p]) {
+                    f = q;
+                    break;
+                }
+        first[p] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ng = 0;
+        for (int p = 0; p < n_planes; ++p) {
+            const int lead = first[p];
+            int g = key[p] ? open_group[lead] : -1;
+            if (g < 0 || out[g].n >= zb) {
+                g = ng++;
+                out[g].n = 0;
+                for (int z = 0; z < 7; ++z) out[g].plane[z] = p;
+                if (key[p]) open_group[lead] = g;
+            }
+            out[g].plane[out[g].n++] = p;
+        }
+        *n_groups = (uint32_t)ng;
+        first[0] = ng;
+    }
+    __syncthreads();
+    const int ng = first[0];
+    for (int g = tid; g < ng; g += 256) groups[g] = out[g];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -819,7 +1057,7 @@ __global__ __launch_bounds__(256, (FLAT == 1 && sizeof(T) == 2 && sizeof(OutT) =
 void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    auto one_item = [&](int plane, const Item &it, const void * = nullptr) {
+    auto one_item = [&](int plane, const Item &it) {
         const int nref = it.nref;
         if (sizeof(OutT) == sizeof(T) && FLAT != 2 && nref <= 1) {
             // nothing to blend: uncovered canvas, or one tile -> the overwrite kernel's pipelined copy
@@ -846,7 +1084,8 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
     if (DYN) {
         // single-tile and blended items cost very differently: the queues (one "rest" queue here, the
         // feather plan is not lane-interleaved) keep every workgroup busy until the end
-        for_each_queued_item(P, n_items, [](int, const Item &) -> const void * { return nullptr; }, one_item);
+        for_each_queued_item<int>(P, n_items, (uint32_t)P.n_planes, [](int, const Item &) -> int { return 0; },
+                                  [&](int plane, const Item &it, const int &) { one_item(plane, it); });
     } else {
         for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
             const int plane = (int)(work / n_items);
@@ -878,6 +1117,32 @@ int launch(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStre
     FuseParams Q = P;
     Q.chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(QUEUE_CHUNK, n_work / (blocks * 16)));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Q, n_items, n_work);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_planes: launch failed: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+// the plane-group kernel: the number of work units (groups x items) is only known on the device, so the grid is
+// the resident workgroups (fewer only when even one plane per group would not fill them)
+template <typename K>
+int launch_zg(K kernel, const FuseParams &P, int64_t n_items, int n_planes, hipStream_t stream, int grid_override) {
+    if (n_items == 0 || n_planes == 0) return SQ_OK;
+    static thread_local std::map<const void *, int> resident;
+    const void *key = reinterpret_cast<const void *>(kernel);
+    auto it = resident.find(key);
+    if (it == resident.end()) {
+        int dev = 0, cus = 256, per_cu = 8;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        it = resident.emplace(key, cus * std::min(per_cu, 8)).first;
+    }
+    const int64_t min_units = n_items * ((n_planes + ZB - 1) / ZB);
+    const int64_t blocks = std::min<int64_t>(min_units, grid_override > 0 ? grid_override : it->second);
+    FuseParams Q = P;
+    Q.chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(QUEUE_CHUNK, min_units / (blocks * 16)));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, stream, Q, n_items);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_fuse_planes: launch failed: %s", hipGetErrorString(e));
     return SQ_OK;
@@ -995,10 +1260,25 @@ extern "C" int sq_selftest_flat_divide_f64(int32_t exponent, int32_t n_binades, 
     return SQ_OK;
 }
 
+// scratch: one uint32 gain class per plane | the nine chunk counters of the work queues, a 128-byte line each |
+// the number of plane groups (a line) | the plane groups (32 bytes per plane at most)
+namespace {
+struct ScratchLayout {
+    int64_t queue, n_groups, groups, total;
+};
+ScratchLayout scratch_layout(int64_t n_planes) {
+    ScratchLayout L;
+    L.queue = (n_planes * 4 + 127) & ~int64_t(127);
+    L.n_groups = L.queue + 9 * QUEUE_STRIDE * 4;
+    L.groups = L.n_groups + 128;
+    L.total = L.groups + n_planes * (int64_t)sizeof(PlaneGroup);
+    return L;
+}
+}  // namespace
+
 extern "C" int64_t sq_fuse_scratch_bytes(int32_t n_planes) {
     if (n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_scratch_bytes: n_planes %d", n_planes);
-    // one uint32 gain class per plane, then the nine chunk counters of the work queues, a 128-byte line each
-    return (((int64_t)n_planes * 4 + 127) & ~int64_t(127)) + 9 * QUEUE_STRIDE * 4;
+    return scratch_layout(n_planes).total;
 }
 
 extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
@@ -1019,7 +1299,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
     if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
-    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC)) || a->grid_blocks < 0 ||
+    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS)) || a->grid_blocks < 0 ||
         ((a->flags & SQ_FUSE_FORCE_QUEUES) && (a->flags & SQ_FUSE_FORCE_STATIC)))
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: flags %d / grid_blocks %d", a->flags, a->grid_blocks);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
@@ -1055,12 +1335,13 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.queue = nullptr;
     P.lane_items = (int32_t)h.lane_items;
     P.n_planes = a->n_planes;
+    const ScratchLayout SL = scratch_layout(a->n_planes);
     if (a->scratch_dev && a->n_planes > 0) {
         if (a->scratch_bytes < sq_fuse_scratch_bytes(a->n_planes))
             return fail(SQ_ERR_WORKSPACE, "sq_fuse_planes: scratch %lld < %lld bytes", (long long)a->scratch_bytes,
                         (long long)sq_fuse_scratch_bytes(a->n_planes));
         if (reinterpret_cast<uintptr_t>(a->scratch_dev) % 128) return fail(SQ_ERR_INVALID, "sq_fuse_planes: scratch not 128-byte aligned");
-        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)sq_fuse_scratch_bytes(a->n_planes), stream) != hipSuccess)
+        if (hipMemsetAsync(a->scratch_dev, 0, (size_t)SL.groups, stream) != hipSuccess)   // classes, counters, group count
             return fail(SQ_ERR_HIP, "sq_fuse_planes: cannot clear the scratch");
         if (flat) {
             // classify every plane's gains once per call (reads H*W*4 (8) B per plane, ~0.4 % of the launch)
@@ -1077,7 +1358,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         const int64_t n_work = (int64_t)a->n_planes * h.n_items;
         // (args->flags can force either one whatever the size -- tests)
         if ((n_work >= 100000 || (a->flags & SQ_FUSE_FORCE_QUEUES)) && n_work < (int64_t(1) << 31) && !(a->flags & SQ_FUSE_FORCE_STATIC))
-            P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + (((int64_t)a->n_planes * 4 + 127) & ~int64_t(127)));
+            P.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(a->scratch_dev) + SL.queue);
     }
     const bool u16 = a->tile_dtype == SQ_U16;
 
@@ -1090,6 +1371,18 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);     \
         return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                 \
     } while (0)
+        if (u16 && flat == 1 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
+            // planes that share a gain image go through the items together (fuse_overwrite_zg_kernel)
+            char *sc = static_cast<char *>(a->scratch_dev);
+            uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
+            PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
+            hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, a->n_planes,
+                               a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
+            P.groups = groups;
+            P.n_groups = n_groups;
+            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            return launch_zg(fuse_overwrite_zg_kernel<false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        }
         if (u16) {
             if (flat == 0) SQ_OVERWRITE(uint16_t, 0);
             if (flat == 1) SQ_OVERWRITE(uint16_t, 1);

@@ -296,9 +296,18 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 #endif
     const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : 0;
     constexpr int NX = 8;
-    const int nblk = tile_h / BLOCK_ROWS + 2;   // row blocks, +1 slack, +1 for the zero-fill bucket
+    // order 4 ("canvas bands"): bucket = the band of BLOCK_ROWS canvas rows an item starts in, zero-fill items
+    // included; spans are visited left to right so that a band's items come out in ascending x
+    const bool bands = order_mode == 4;
+    const int nblk = (bands ? canvas_h : tile_h) / BLOCK_ROWS + 2;   // buckets, +1 slack, +1 for the zero-fill bucket
+    std::vector<size_t> span_order(spans.size());
+    for (size_t i = 0; i < spans.size(); ++i) span_order[i] = i;
+    if (bands)
+        std::stable_sort(span_order.begin(), span_order.end(),
+                         [&](size_t a, size_t b) { return spans[a].dst_x < spans[b].dst_x; });
     auto for_each_item = [&](auto &&emit) {
-        for (size_t si = 0; si < spans.size(); ++si) {
+        for (size_t so = 0; so < spans.size(); ++so) {
+            const size_t si = span_order[so];
             const Span &sp = spans[si];
             const Ref *rf = (mode == SQ_FUSE_OVERWRITE && sp.nref) ? &refs[sp.ref0] : nullptr;
             for (int r0 = 0; r0 < sp.h; r0 += BLOCK_ROWS)
@@ -322,11 +331,14 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 }
         }
     };
-    auto key_of = [&](const Item &it) { return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1; };
+    auto key_of = [&](const Item &it) {
+        if (bands) return std::min(it.dst_y / BLOCK_ROWS, nblk - 2);
+        return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1;
+    };
     std::vector<int64_t> count(nblk, 0);
     int64_t n_items = 0;
     for_each_item([&](const Item &it) {
-        ++count[order_mode ? key_of(it) : 0];
+        ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4) ? key_of(it) : 0];
         ++n_items;
     });
     const auto t_items = std::chrono::steady_clock::now();
@@ -362,6 +374,14 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     if (order_mode == 0) {
         int64_t i = 0;
         for_each_item([&](const Item &it) { dst[i++] = it; });
+    } else if (order_mode == 3) {
+        // canvas raster order: bands of BLOCK_ROWS canvas rows, left to right; zero-fill items in place
+        int64_t i = 0;
+        for_each_item([&](const Item &it) { dst[i++] = it; });
+        std::stable_sort(dst, dst + n_items, [](const Item &a, const Item &b) {
+            const int ba = a.dst_y / BLOCK_ROWS, bb = b.dst_y / BLOCK_ROWS;
+            return ba != bb ? ba < bb : a.dst_x < b.dst_x;
+        });
     } else {
         // position of the k-th item of bucket `key` in the row-block-sorted list ...
         std::vector<int64_t> start(nblk + 1, 0);
@@ -380,7 +400,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             tail_at[x] = tail;
             tail += lane_len[x] - common;
         }
-        if (order_mode == 2) {   // the header is already in the table: patch the field
+        if (order_mode == 2 || order_mode == 4) {   // the header is already in the table: patch the field
             hd.lane_items = common;
             std::memcpy(plan->table.ptr, &hd, sizeof hd);
         }

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get('SQ_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsqui
 SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
-SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC = 1, 2
+SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS = 1, 2, 4
 SQ_VERSION = 101
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
@@ -275,10 +275,17 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
     """
     import torch
     L = lib()
-    if not canvas.is_cuda or not canvas.is_contiguous():
-        raise ValueError("canvas must be a contiguous device tensor")
     hc, wc = int(canvas.shape[-2]), int(canvas.shape[-1])
     n_planes = int(canvas.numel() // (hc * wc)) if hc * wc else 0
+    # contiguous, or [P, Hc, Wc] with dense rows and any row pitch / plane stride (empty_canvas pads the plane stride)
+    pitch, plane_stride = wc, hc * wc
+    if not canvas.is_cuda:
+        raise ValueError("canvas must be a device tensor")
+    if not canvas.is_contiguous():
+        if canvas.dim() != 3 or (wc > 1 and canvas.stride(2) != 1) or canvas.stride(1) < wc or \
+                (n_planes > 1 and canvas.stride(0) < (hc - 1) * canvas.stride(1) + wc):
+            raise ValueError("canvas must be contiguous or a [P, Hc, Wc] tensor with unit-stride rows and non-overlapping planes")
+        pitch, plane_stride = int(canvas.stride(1)), int(canvas.stride(0))
     a = _FuseArgs()
     a.plan = plan.handle
     table = plan.device_table(canvas.device)
@@ -329,8 +336,8 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
         a.scratch_dev = scratch.data_ptr()
         a.scratch_bytes = scratch.numel()
     a.canvas_dev = canvas.data_ptr()
-    a.canvas_plane_stride = hc * wc
-    a.canvas_h, a.canvas_w, a.canvas_pitch = hc, wc, wc
+    a.canvas_plane_stride = plane_stride
+    a.canvas_h, a.canvas_w, a.canvas_pitch = hc, wc, pitch
     a.canvas_dtype = sq_dtype_of(np_dtype_of_torch(canvas.dtype))
     a.n_planes = n_planes
     a.mode = plan.mode
@@ -339,6 +346,33 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
         for t in keep:
             t.record_stream(stream)
     _check(L.sq_fuse_planes(C.byref(a), _stream_ptr(stream)), 'sq_fuse_planes')
+
+
+PLANE_ALIGN_BYTES = 128
+
+
+def empty_canvas(n_planes: int, hc: int, wc: int, dtype, device):
+    """Uninitialised device canvas [n_planes, hc, wc] with dense rows (pitch = wc, like the reference's array)
+    whose PLANE stride is rounded up to a multiple of 128 bytes: every plane then starts on a cache-line
+    boundary, so the rows of all planes sit at the same phase inside a line and the fusion kernel can carry the
+    planes that share a gain image through an item together (fuse.hip, plane groups).  Each plane ``canvas[p]`` is
+    contiguous; the tensor as a whole is not."""
+    import torch
+    esz = torch.empty((), dtype=dtype).element_size()
+    unit = PLANE_ALIGN_BYTES // esz
+    stride = -(-(hc * wc) // unit) * unit
+    flat = torch.empty(max(1, n_planes * stride), dtype=dtype, device=device)
+    return flat.as_strided((n_planes, hc, wc), (stride, wc, 1))
+
+
+def planes_to_host(canvas):
+    """Device planes [P, Hc, Wc] (any plane stride) -> contiguous numpy array, one D2H copy per plane (a strided
+    ``.cpu()`` would first build a contiguous copy ON the device)."""
+    import torch
+    out = torch.empty(tuple(canvas.shape), dtype=canvas.dtype)
+    for p in range(canvas.shape[0]):
+        out[p].copy_(canvas[p])
+    return out.numpy()
 
 
 def _tile_table(tiles, tile_ptrs, shape, np_dtype):

@@ -239,7 +239,9 @@ class PlaneStreamWriter:
         # page-locking host memory costs more than a small region's whole fusion, so callers that write
         # many regions (one per well and timepoint) hand them on
         if buffers is None:
-            buffers = ([[torch.empty((self.batch,) + s, dtype=tdtype, device=device) for s in yx] for _ in range(slots)],
+            # level 0 = the fusion canvas: dense rows, planes on 128-byte lines (native.empty_canvas)
+            buffers = ([[native.empty_canvas(self.batch, s[0], s[1], tdtype, device) if lv == 0 else
+                         torch.empty((self.batch,) + s, dtype=tdtype, device=device) for lv, s in enumerate(yx)] for _ in range(slots)],
                        [[torch.empty((self.batch,) + s, dtype=tdtype, pin_memory=True) for s in yx] for _ in range(slots)])
         self.buffers = buffers
         self._dev, self._host = buffers
@@ -305,7 +307,11 @@ class PlaneStreamWriter:
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(fused)
             for d, h in zip(dev, self._host[slot]):
-                h[:m].copy_(d[:m], non_blocking=True)
+                if d.is_contiguous():
+                    h[:m].copy_(d[:m], non_blocking=True)
+                else:                       # padded plane stride: every plane is contiguous, the stack is not
+                    for p in range(m):
+                        h[p].copy_(d[p], non_blocking=True)
             event.record()
         self._free[slot].clear()
         self._queue.put((slot, list(coords), event))

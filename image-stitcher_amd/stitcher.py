@@ -554,8 +554,10 @@ class Stitcher:
         """Fuse one (timepoint, region) -> 5-D TCZYX array of the input dtype
         (stitcher.py:639-689).  Returns numpy (host) unless ``device_output``."""
         planes, _ = self.stitch_planes(timepoint, region, None, progress_callback)
-        canvas = planes.view(1, self.num_c, self.num_z, planes.shape[-2], planes.shape[-1])
-        return canvas if device_output else canvas.cpu().numpy()
+        shape = (1, self.num_c, self.num_z, planes.shape[-2], planes.shape[-1])
+        if device_output:       # a strided view: planes sit on 128-byte lines, rows are dense
+            return planes.unflatten(0, (self.num_c, self.num_z)).unsqueeze(0)
+        return native.planes_to_host(planes).reshape(shape)
 
     def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None):
         """Fuse the (channel, z) planes ``only_planes`` (plane = channel * num_z + z; None = all) of one
@@ -576,8 +578,9 @@ class Stitcher:
         slot_of = {p: i for i, p in enumerate(plane_ids)}
         print(f"region {region} timepoint {timepoint} output array dimensions: "
               f"{(1, self.num_c, self.num_z, height, width)}" + ("" if only_planes is None else f", planes {plane_ids}"))
+        # dense rows like the reference's array, every plane on a 128-byte line (native.empty_canvas)
         flat_canvas = None if stream_to is not None else \
-            torch.empty((len(plane_ids), height, width), dtype=native.torch_dtype_of(self.dtype), device=self.device)
+            native.empty_canvas(len(plane_ids), height, width, native.torch_dtype_of(self.dtype), self.device)
         hc, wc = height, width
         th, tw = self.input_height, self.input_width
         total_tiles = len(region_data)

@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--drift', type=int, nargs=2, default=[3, -2])
     ap.add_argument('--rcp', action='store_true', help='gains as [2, H, W]: gains, then correctly rounded reciprocals (-DSQ_RCP_TABLE=1 builds)')
     ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
+    ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
+    ap.add_argument('--flags', type=int, default=0)
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g, T = a.grid, a.tile
@@ -43,7 +45,8 @@ def main():
                 desc[r * g + c] = (spec.scene_seed(0, 0, p, 0) % 2**64, spec.noise_seed(0, 0, p, 0, r * g + c) % 2**64, oy, ox)
         native.synth_tiles(desc, T, T, 200, 'uint16', dev, out=tiles[p])
     torch.cuda.synchronize()
-    canvas = torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)
+    canvas = native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else \
+        torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)
     flats = None
     if a.flat != 'none':
         g = synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)
@@ -53,13 +56,13 @@ def main():
             ffs = [torch.from_numpy(g).to(dev) for _ in range(a.nflats)]
         flats = [ffs[p * a.nflats // a.planes] for p in range(a.planes)]
     for _ in range(2):
-        native.fuse_planes(plan, tiles, canvas, flats)
+        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags)
     torch.cuda.synchronize()
     evs = []
     for _ in range(a.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        native.fuse_planes(plan, tiles, canvas, flats)
+        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags)
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
@@ -69,7 +72,9 @@ def main():
     if a.check:
         from oracle import stitch_oracle as O
         want = O.fuse_plane_overwrite(list(tiles[0].cpu().numpy()), rects, hc, wc, None if flats is None else g)
-        print('plane 0 mismatched voxels vs oracle:', int(np.count_nonzero(canvas[0].cpu().numpy() != want)))
+        for p in sorted({0, a.planes - 1}):
+            want_p = want if p == 0 else O.fuse_plane_overwrite(list(tiles[p].cpu().numpy()), rects, hc, wc, None if flats is None else g)
+            print(f'plane {p} mismatched voxels vs oracle:', int(np.count_nonzero(canvas[p].cpu().numpy() != want_p)))
     print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
           f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
 

@@ -68,6 +68,120 @@ __global__ __launch_bounds__(256) void read_linear(const u32x4 *src, size_t n_ch
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) *sink = 1;
 }
+// persistent grid, every WAVE takes the next U KiB in address order from one atomic counter (what the hardware's
+// own workgroup dispatcher does for a one-shot grid)
+template <int U, bool NTS>
+__global__ __launch_bounds__(256) void copy_dynamic(const u32x4 *src, u32x4 *dst, size_t n_chunks, unsigned *counter) {
+    const int lane = threadIdx.x & 63;
+    unsigned c = 0;
+    if (lane == 0) c = atomicAdd(counter, 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    while (c < n_chunks) {
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(counter, 1u);   // asked for before this chunk is moved
+        const size_t base = (size_t)c * (64 * U) + lane;
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = ld<false>(src + base + k * 64);
+#pragma unroll
+        for (int k = 0; k < U; ++k) st<NTS>(dst + base + k * 64, v[k]);
+        c = __builtin_amdgcn_readfirstlane(nxt);
+    }
+}
+// one-shot grid whose blocks take chunks in a scattered order: S streams, each sequential
+template <int U>
+__global__ __launch_bounds__(256) void copy_perm(const u32x4 *src, u32x4 *dst, size_t n_chunks, unsigned S) {
+    const size_t b = blockIdx.x;
+    const size_t c = (b % S) * (n_chunks / S) + b / S;
+    const size_t base = c * (256 * U) + threadIdx.x;
+    u32x4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = ld<false>(src + base + k * 256);
+#pragma unroll
+    for (int k = 0; k < U; ++k) st<true>(dst + base + k * 256, v[k]);
+}
+// one-shot U=1 whose waves wait for their store's acknowledgement before they end
+__global__ __launch_bounds__(256) void copy_oneshot_wait(const u32x4 *src, u32x4 *dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    st<true>(dst + i, ld<false>(src + i));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// persistent grid-stride whose waves wait for every store's acknowledgement at the end of each chunk
+template <int U>
+__global__ __launch_bounds__(256) void copy_linear_wait(const u32x4 *src, u32x4 *dst, size_t n_chunks) {
+    for (size_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const size_t base = c * (256 * U) + threadIdx.x;
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = ld<false>(src + base + k * 256);
+#pragma unroll
+        for (int k = 0; k < U; ++k) st<true>(dst + base + k * 256, v[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+// persistent grid, chunks of 256 x U vectors handed to WORKGROUPS in address order by one atomic counter; the
+// atomic for the next chunk is issued before the current one is moved
+template <int U>
+__global__ __launch_bounds__(256) void copy_dynamic_wg(const u32x4 *src, u32x4 *dst, size_t n_chunks, unsigned *counter) {
+    __shared__ unsigned s_c[2];
+    if (threadIdx.x == 0) s_c[0] = atomicAdd(counter, 1u);
+    for (int it = 0;; ++it) {
+        __syncthreads();
+        const unsigned c = s_c[it & 1];
+        if (c >= n_chunks) break;
+        unsigned nxt = 0;
+        if (threadIdx.x == 0) nxt = atomicAdd(counter, 1u);
+        const size_t base = (size_t)c * (256 * U) + threadIdx.x;
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = ld<false>(src + base + k * 256);
+#pragma unroll
+        for (int k = 0; k < U; ++k) st<true>(dst + base + k * 256, v[k]);
+        if (threadIdx.x == 0) s_c[(it + 1) & 1] = nxt;
+    }
+}
+// loader / storer split: waves 0,1 only LOAD (global -> registers -> an LDS ring), waves 2,3 only STORE (ring ->
+// registers -> global).  A loader's vmcnt then never covers a store, so no wave ever waits for a store to be
+// acknowledged.  Pair i = (wave i, wave i + 2) has a private ring of NS 1-KiB slots and two monotonic LDS counters.
+// Stream s = 2 * block + pair moves the 1-KiB units s, s + S, s + 2S, ... (S = 2 * gridDim.x).
+template <int NS, int K>
+__global__ __launch_bounds__(256) void copy_split(const u32x4 *src, u32x4 *dst, size_t n_units) {
+    __shared__ u32x4 ring[2][NS][64];
+    __shared__ volatile unsigned filled[2], drained[2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, pair = wave & 1;
+    if (threadIdx.x < 2) filled[threadIdx.x] = drained[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t S = 2 * (size_t)gridDim.x, s0 = 2 * (size_t)blockIdx.x + pair;
+    const unsigned total = s0 < n_units ? (unsigned)((n_units - s0 + S - 1) / S) : 0;
+    if (wave < 2) {
+        u32x4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((unsigned)k < total) v[k] = ld<false>(src + (s0 + k * S) * 64 + lane);
+        for (unsigned j = 0; j < total; j += K) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const unsigned jj = j + k;
+                if (jj < total) {
+                    while (jj - drained[pair] >= (unsigned)NS) __builtin_amdgcn_s_sleep(1);
+                    ring[pair][jj % NS][lane] = v[k];
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) filled[pair] = jj + 1;   // LDS operations of one wave execute in order
+                    if (jj + K < total) v[k] = ld<false>(src + (s0 + (size_t)(jj + K) * S) * 64 + lane);
+                }
+            }
+        }
+    } else {
+        for (unsigned j = 0; j < total; ++j) {
+            while (filled[pair] <= j) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const u32x4 x = ring[pair][j % NS][lane];
+            asm volatile("" ::: "memory");
+            if (lane == 0) drained[pair] = j + 1;
+            st<true>(dst + (s0 + (size_t)j * S) * 64 + lane, x);
+        }
+    }
+}
 // Z streams `zstride` vectors apart; a block copies chunk c of stream 0, 1, ..., Z-1 before moving on
 template <int U, int Z>
 __global__ __launch_bounds__(256) void copy_zinter(const u32x4 *src, u32x4 *dst, size_t n_chunks, size_t zstride) {
@@ -91,14 +205,23 @@ __global__ __launch_bounds__(256) void copy_zinter(const u32x4 *src, u32x4 *dst,
 // order 0: tile-major items; order 1: row-block-major (all tiles' block b, then b+1): the product's order
 template <int ALIGN, int Z>
 __global__ __launch_bounds__(256) void copy_rows(const char *src, char *dst, int G, int T, int CR, size_t pitch, int order,
-                                                 size_t n_items, size_t src_z, size_t dst_z) {
+                                                 size_t n_items, size_t src_z, size_t dst_z, unsigned *counter) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rows = T - 2 * CR, seg = rows * 2;   // bytes per row segment
     const int nblk = (rows + 7) / 8;
-    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    __shared__ unsigned s_next;
+    for (size_t it = blockIdx.x; it < n_items;) {
+        if (counter) {   // dynamic: items in list order from one atomic counter
+            __syncthreads();
+            if (threadIdx.x == 0) s_next = atomicAdd(counter, 1u);
+            __syncthreads();
+            it = s_next;
+            if (it >= n_items) break;
+        }
         int tile, blk;
         if (order == 0) { tile = (int)(it / nblk); blk = (int)(it % nblk); }
-        else { blk = (int)(it / (G * G)); tile = (int)(it % (G * G)); }
+        else if (order == 1) { blk = (int)(it / (G * G)); tile = (int)(it % (G * G)); }
+        else { const int tx = (int)(it % G); blk = (int)((it / G) % nblk); tile = (int)(it / G / nblk) * G + tx; }   // canvas raster
         const int ty = tile / G, tx = tile % G;
         for (int r = blk * 8 + wave; r < min(rows, blk * 8 + 8); r += 4) {
             const char *s = src + (size_t)tile * T * T * 2 + (size_t)(CR + r) * T * 2 + CR * 2;
@@ -132,6 +255,7 @@ __global__ __launch_bounds__(256) void copy_rows(const char *src, char *dst, int
                     *(G1 uint16_t *)(d + z * dst_z + tail0 + lane * 2) = *(const G1 uint16_t *)(s + z * src_z + tail0 + lane * 2);
             }
         }
+        if (!counter) it += gridDim.x;
     }
 }
 
@@ -195,6 +319,60 @@ int main(int argc, char **argv) {
     COPY(8, false, true, 8);
     COPY(8, false, false, 8);
     COPY(16, false, true, 4);
+    unsigned *counter;
+    CK(hipMalloc(&counter, 4));
+#define DYN(U, PER_CU)                                                                                              \
+    do {                                                                                                            \
+        const size_t nch = nvec / (64 * U);                                                                         \
+        double ms = time_ms([&] { CK(hipMemsetAsync(counter, 0, 4, 0)); hipLaunchKernelGGL((copy_dynamic<U, true>), dim3(cus * PER_CU), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nch, counter); }); \
+        snprintf(name, sizeof name, "copy U=%d per WAVE from one atomic counter, %d/CU persistent", U, PER_CU);     \
+        report(name, ms, 2.0 * bytes);                                                                              \
+    } while (0)
+#define PERM(U, S)                                                                                                  \
+    do {                                                                                                            \
+        const size_t nch = nvec / (256 * U);                                                                        \
+        double ms = time_ms([&] { hipLaunchKernelGGL((copy_perm<U>), dim3((unsigned)nch), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nch, S); }); \
+        snprintf(name, sizeof name, "copy U=%d one-shot, blocks dealt over %d sequential streams", U, S);           \
+        report(name, ms, 2.0 * bytes);                                                                              \
+    } while (0)
+    {
+        double ms = time_ms([&] { hipLaunchKernelGGL(copy_oneshot_wait, dim3((unsigned)(nvec / 256)), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst); });
+        report("copy U=1 one-shot, vmcnt(0) before the wave ends", ms, 2.0 * bytes);
+        ms = time_ms([&] { hipLaunchKernelGGL((copy_linear_wait<4>), dim3(cus * 8), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nvec / 1024); });
+        report("copy U=4 8/CU persistent, vmcnt(0) after every chunk", ms, 2.0 * bytes);
+        ms = time_ms([&] { hipLaunchKernelGGL((copy_linear_wait<8>), dim3(cus * 8), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nvec / 2048); });
+        report("copy U=8 8/CU persistent, vmcnt(0) after every chunk", ms, 2.0 * bytes);
+    }
+#define DYNWG(U, PER_CU)                                                                                            \
+    do {                                                                                                            \
+        const size_t nch = nvec / (256 * U);                                                                        \
+        double ms = time_ms([&] { CK(hipMemsetAsync(counter, 0, 4, 0)); hipLaunchKernelGGL((copy_dynamic_wg<U>), dim3(cus * PER_CU), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nch, counter); }); \
+        snprintf(name, sizeof name, "copy U=%d per WORKGROUP from one atomic counter, %d/CU persistent", U, PER_CU); \
+        report(name, ms, 2.0 * bytes);                                                                              \
+    } while (0)
+    DYNWG(4, 8);
+    DYNWG(8, 8);
+    DYNWG(16, 4);
+#define SPLIT(NS, K, PER_CU)                                                                                        \
+    do {                                                                                                            \
+        double ms = time_ms([&] { hipLaunchKernelGGL((copy_split<NS, K>), dim3(cus * PER_CU), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nvec / 64); }); \
+        snprintf(name, sizeof name, "copy loader/storer waves, ring %d x 1 KiB, %d loads in flight, %d/CU persistent", NS, K, PER_CU); \
+        report(name, ms, 2.0 * bytes);                                                                              \
+    } while (0)
+    SPLIT(16, 4, 4);
+    SPLIT(16, 4, 5);
+    SPLIT(16, 8, 4);
+    SPLIT(8, 4, 8);
+    SPLIT(8, 2, 8);
+    SPLIT(8, 8, 8);
+    SPLIT(4, 4, 8);
+    PERM(1, 1);
+    PERM(1, 16);
+    PERM(1, 256);
+    PERM(1, 4096);
+    PERM(1, 65536);
+    PERM(4, 16);
+    PERM(4, 256);
     {
         const size_t nch = nvec / (256 * 4);
         double ms = time_ms([&] { hipLaunchKernelGGL((fill_linear<4, true>), dim3(cus * 8), dim3(256), 0, 0, (u32x4 *)dst, nch); });
@@ -236,22 +414,34 @@ int main(int argc, char **argv) {
             const int nplanes = (int)std::min(bytes / plane_src, bytes / plane_dst);
             const size_t n_items = (size_t)G * G * ((rows + 7) / 8);
             const double moved = 2.0 * G * G * (double)rows * rows * 2;
-#define ROWS(ALIGN, Z, ORDER)                                                                                        \
+            // MODE 0: persistent 8/CU grid-stride; 1: one-shot (a block per item); 2: persistent, items from one atomic counter
+#define ROWS(ALIGN, Z, ORDER, MODE)                                                                                  \
     do {                                                                                                             \
         if (nplanes >= Z) {                                                                                          \
             double ms = time_ms([&] {                                                                                \
-                for (int p = 0; p + Z <= nplanes; p += Z)                                                            \
-                    hipLaunchKernelGGL((copy_rows<ALIGN, Z>), dim3(cus * 8), dim3(256), 0, 0, src + p * plane_src, dst + p * plane_dst, G, T, CR, pitch, ORDER, n_items, plane_src, plane_dst); \
+                for (int p = 0; p + Z <= nplanes; p += Z) {                                                          \
+                    if (MODE == 2) CK(hipMemsetAsync(counter, 0, 4, 0));                                             \
+                    hipLaunchKernelGGL((copy_rows<ALIGN, Z>), dim3(MODE == 1 ? (unsigned)n_items : cus * 8), dim3(256), 0, 0, src + p * plane_src, dst + p * plane_dst, G, T, CR, pitch, ORDER, n_items, plane_src, plane_dst, MODE == 2 ? counter : nullptr); \
+                }                                                                                                    \
             });                                                                                                      \
-            snprintf(name, sizeof name, "rows 3608 B, pitch %zu, align %d, Z=%d, order %d, %d planes", pitch, ALIGN, Z, ORDER, nplanes / Z * Z); \
+            snprintf(name, sizeof name, "rows 3608 B, pitch %zu, align %d, Z=%d, order %d, mode %d, %d planes", pitch, ALIGN, Z, ORDER, MODE, nplanes / Z * Z); \
             report(name, ms, moved * (nplanes / Z * Z));                                                             \
         }                                                                                                            \
     } while (0)
-            ROWS(0, 1, 0);
-            ROWS(1, 1, 0);
-            ROWS(1, 1, 1);
-            ROWS(1, 2, 1);
-            ROWS(1, 3, 1);
+            ROWS(0, 1, 0, 0);
+            ROWS(0, 1, 0, 1);
+            ROWS(0, 1, 0, 2);
+            ROWS(0, 1, 1, 0);
+            ROWS(0, 1, 1, 1);
+            ROWS(0, 1, 1, 2);
+            ROWS(0, 1, 2, 0);
+            ROWS(0, 1, 2, 1);
+            ROWS(0, 1, 2, 2);
+            ROWS(1, 1, 2, 1);
+            ROWS(1, 1, 2, 2);
+            ROWS(0, 2, 2, 1);
+            ROWS(0, 2, 2, 2);
+            ROWS(0, 3, 2, 2);
         }
     }
     return 0;
