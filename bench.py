@@ -72,8 +72,8 @@ def main():
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
-                    help='cfg4: write {plane: SHA-256 of its fused canvas} of the last step to this JSON file (one file per '
-                         'rank, ".rankR" appended); slow, for the N-rank == 1-rank check, not for timing')
+                    help='cfg4: write {plane: position-weighted digest of its fused canvas} of the last step to this JSON '
+                         'file (one file per rank, ".rankR" appended); for the N-rank == 1-rank check, not for timing')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else the committed measurement)')
     args = ap.parse_args()
@@ -93,8 +93,14 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     backend = os.environ.get('SQ_DIST_BACKEND', 'nccl')   # 'gloo' only to rehearse N > 1 on a 1-GPU box
-    if world > 1:
+    # SQ_BENCH_FORCE_DIST=1: open the process group (and run the collectives) with ONE rank too -- the only way to
+    # take the RCCL branch on a one-GPU box (torchrun --nproc-per-node 1, or plain python with the env below)
+    force_dist = bool(os.environ.get('SQ_BENCH_FORCE_DIST'))
+    if world > 1 or force_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if force_dist and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+            os.environ['SQ_DIST_FORCE_COLLECTIVE'] = '1'
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -112,7 +118,7 @@ def main():
         out = run_region(ctx)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -143,6 +149,20 @@ def plane_desc(spec, g, c, z):
             oy, ox = spec.origin(r, col)
             desc[r * g + col] = (scene, spec.noise_seed(0, 0, z, c, spec.fov_index(r, col)) % 2 ** 64, oy, ox)
     return desc
+
+
+def plane_digest(plane, rows_per_chunk=2048):
+    """Order-sensitive 61-bit digest of a uint16 device plane, computed on the device chunk by chunk."""
+    import torch
+    mod = (1 << 61) - 1
+    h, w = plane.shape
+    weights = (torch.arange(rows_per_chunk * w, device=plane.device, dtype=torch.int64) % 65521) + 1
+    d = 0
+    for r0 in range(0, h, rows_per_chunk):
+        chunk = plane[r0:r0 + rows_per_chunk].contiguous().view(torch.int16).to(torch.int64).flatten() & 0xFFFF
+        s = int((chunk * weights[:chunk.numel()]).sum().item())
+        d = (d * 1000003 + s) % mod
+    return d
 
 
 def algorithmic_bytes(n_planes, covered, hc, wc, flat):
@@ -454,9 +474,11 @@ def run_job(ctx):
             plans[key] = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE)
         return plans[key]
 
+    multi = world > 1 or dist.is_initialized()
+
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -490,9 +512,8 @@ def run_job(ctx):
             if record:
                 fuse_events.append((e0, e1, len(b)))
             if args.sha_out and record == 'last':
-                import hashlib
                 for k, p in enumerate(b):
-                    state.setdefault('sha', {})[int(p)] = hashlib.sha256(canvas[k].cpu().numpy().tobytes()).hexdigest()
+                    state.setdefault('sha', {})[int(p)] = plane_digest(canvas[k])
         state['plan'], state['shifts'] = plan, shifts
         return timed
 
@@ -506,7 +527,7 @@ def run_job(ctx):
         with open(f'{args.sha_out}.rank{rank}', 'w') as fh:
             json.dump(state.get('sha', {}), fh)
     mine_s = seconds
-    if world > 1:
+    if multi:
         t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
@@ -520,7 +541,7 @@ def run_job(ctx):
     alg = algorithmic_bytes(1, plan.covered_voxels, hc, wc, True)
     achieved = alg * npl.sum() / (ms.sum() * 1e-3) / 1e9 if ms.sum() > 0 else 0.0
     fracs = [achieved / HBM_PEAK_GBS]
-    if world > 1:      # every rank's fraction, for the record
+    if multi:      # every rank's fraction, for the record
         t = torch.tensor([achieved / HBM_PEAK_GBS], dtype=torch.float64, device=coll_dev or 'cpu')
         allf = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allf, t)

@@ -39,16 +39,25 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
 
-constexpr int MAX_POW2 = 4096;     // longest power-of-two line handled in LDS
-constexpr int MAX_DIRECT = 2048;   // longest non-power-of-two line (direct DFT, O(n^2))
+constexpr int MAX_LINE = 4096;     // longest line: a power of two runs in place in LDS; any other length n runs as a
+                                   // Bluestein (chirp-z) convolution through a power-of-two FFT of M >= 2n - 1 <= 8192 points
+constexpr int MAX_BLUESTEIN_M = 8192;
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+inline int bluestein_m(int n) {   // 0 for a power of two (no chirp needed)
+    if (is_pow2(n)) return 0;
+    int m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    return m;
+}
 inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
 
 // Workspace carve-up, identical on host (sizes) and device (pointers).
 struct Layout {
     int64_t tw0, tw1, up0, up1, spectra, amps, rowmax, d1, ccup, peak, total;
+    int64_t twm0, twm1, chirp0, chirp1, cspec0, cspec1;   // Bluestein tables per axis (unused for a power of two)
     int n0, n1, n1h, region, up;
+    int m0, m1;      // Bluestein FFT length per axis, 0 = the axis length is a power of two
     int64_t per_pair_spec;
 };
 
@@ -68,6 +77,20 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     off += align16((int64_t)n0 * up * 16);
     L.up1 = off;
     off += align16((int64_t)n1 * up * 16);
+    L.m0 = bluestein_m(n0);
+    L.m1 = bluestein_m(n1);
+    L.twm0 = off;
+    off += (int64_t)L.m0 * 16;
+    L.twm1 = off;
+    off += (int64_t)L.m1 * 16;
+    L.chirp0 = off;
+    off += L.m0 ? align16((int64_t)n0 * 16) : 0;
+    L.chirp1 = off;
+    off += L.m1 ? align16((int64_t)n1 * 16) : 0;
+    L.cspec0 = off;
+    off += (int64_t)L.m0 * 16;
+    L.cspec1 = off;
+    off += (int64_t)L.m1 * 16;
     L.per_pair_spec = (int64_t)n0 * L.n1h * 16;
     L.spectra = off;
     off += 2 * L.per_pair_spec * n_pairs;
@@ -99,6 +122,24 @@ struct RegParams {
     int32_t n_tiles, tile_h, tile_w;
 };
 
+// tables of the Bluestein form of a line FFT (see lines_fft)
+struct Chirp {
+    int m;                 // 0: power of two, no chirp
+    const cplx *twm;       // exp(-2 pi i k / m)
+    const cplx *w;         // w[j], j < n
+    const cplx *spec;      // FFT_m of conj(w) laid out circularly
+};
+
+__device__ __forceinline__ Chirp chirp_of(const RegParams &P, int axis) {
+    const Layout &L = P.L;
+    Chirp C;
+    C.m = axis ? L.m1 : L.m0;
+    C.twm = reinterpret_cast<const cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
+    C.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
+    C.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
+    return C;
+}
+
 // A pair whose tile index or crop origin would read outside its tile never touches memory: its crops
 // are taken as zero and its result carries coarse = INT32_MIN (the pair table lives in device memory,
 // so the host cannot validate it before the launch).
@@ -119,7 +160,6 @@ __device__ __forceinline__ bool pair_ok(const RegParams &P, const sq_pair &pr) {
 // is that of the plain radix-2 schedule, with half the LDS passes and barriers.  All `nlines` lines
 // of the block (contiguous, n points each) go through every pass together: one barrier per pass for
 // the whole batch instead of one per line.
-// Otherwise: direct DFT with tw[j] = exp(-2 pi i j / n), j < n, line by line, result written back via tmp.
 // INV conjugates the twiddles (no 1/n scaling anywhere: only argmax and ratios are used).
 template <bool INV>
 __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
@@ -129,78 +169,100 @@ __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
 }
 
 template <bool INV>
-__device__ void lines_fft(cplx *base, cplx *tmp, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
-    if ((n & (n - 1)) == 0) {
-        const int logn = 31 - __clz(n);
-        for (int e = tid; e < nlines * n; e += nt) {
-            const int i = e & (n - 1);
-            const int j = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
-            if (i < j) {
-                cplx *x = base + (e - i);
-                const cplx a = x[i];
-                x[i] = x[j];
-                x[j] = a;
-            }
+__device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
+    const int logn = 31 - __clz(n);
+    for (int e = tid; e < nlines * n; e += nt) {
+        const int i = e & (n - 1);
+        const int j = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
+        if (i < j) {
+            cplx *x = base + (e - i);
+            const cplx a = x[i];
+            x[i] = x[j];
+            x[j] = a;
+        }
+    }
+    __syncthreads();
+    int s = 1;
+    if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
+        for (int e = tid; e < nlines * (n >> 1); e += nt) {
+            cplx *x = base + 2 * (int64_t)e;
+            const cplx t = cmul(twiddle<INV>(tw, 0), x[1]);
+            const cplx u = x[0];
+            x[0] = cadd(u, t);
+            x[1] = csub(u, t);
         }
         __syncthreads();
-        int s = 1;
-        if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
-            for (int e = tid; e < nlines * (n >> 1); e += nt) {
-                cplx *x = base + 2 * (int64_t)e;
-                const cplx t = cmul(twiddle<INV>(tw, 0), x[1]);
-                const cplx u = x[0];
-                x[0] = cadd(u, t);
-                x[1] = csub(u, t);
-            }
-            __syncthreads();
-            s = 2;
+        s = 2;
+    }
+    const int quads = n >> 2;
+    for (; s < logn; s += 2) {
+        const int half = 1 << (s - 1);
+        const int ts1 = n >> s, ts2 = n >> (s + 1);
+        for (int e = tid; e < nlines * quads; e += nt) {
+            const int l = e / quads, q = e - l * quads;
+            const int k = q & (half - 1);
+            cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
+            const cplx w1 = twiddle<INV>(tw, k * ts1);
+            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
+            const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
+            // stage s: (x0, x1) and (x2, x3), both with w1
+            const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
+            const cplx a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
+            // stage s + 1: (a0, a2) with w2, (a1, a3) with w3
+            const cplx u2 = cmul(w2, a2), u3 = cmul(w3, a3);
+            x[0] = cadd(a0, u2);
+            x[2 * half] = csub(a0, u2);
+            x[half] = cadd(a1, u3);
+            x[3 * half] = csub(a1, u3);
         }
-        const int quads = n >> 2;
-        for (; s < logn; s += 2) {
-            const int half = 1 << (s - 1);
-            const int ts1 = n >> s, ts2 = n >> (s + 1);
-            for (int e = tid; e < nlines * quads; e += nt) {
-                const int l = e / quads, q = e - l * quads;
-                const int k = q & (half - 1);
-                cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
-                const cplx w1 = twiddle<INV>(tw, k * ts1);
-                const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
-                const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
-                // stage s: (x0, x1) and (x2, x3), both with w1
-                const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
-                const cplx a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
-                // stage s + 1: (a0, a2) with w2, (a1, a3) with w3
-                const cplx u2 = cmul(w2, a2), u3 = cmul(w3, a3);
-                x[0] = cadd(a0, u2);
-                x[2 * half] = csub(a0, u2);
-                x[half] = cadd(a1, u3);
-                x[3 * half] = csub(a1, u3);
-            }
-            __syncthreads();
-        }
-    } else {
-        for (int l = 0; l < nlines; ++l) {
-            cplx *x = base + (int64_t)l * n;
-            for (int k = tid; k < n; k += nt) {
-                cplx acc = {0.0, 0.0};
-                int idx = 0;
-                for (int j = 0; j < n; ++j) {
-                    acc = cadd(acc, cmul(x[j], twiddle<INV>(tw, idx)));
-                    idx += k;
-                    if (idx >= n) idx -= n;
-                }
-                tmp[k] = acc;
-            }
-            __syncthreads();
-            for (int k = tid; k < n; k += nt) x[k] = tmp[k];
-            __syncthreads();
-        }
+        __syncthreads();
     }
 }
 
+// Any other length n: Bluestein's chirp-z form of the same DFT, in place in a line of M >= 2n - 1 points (M a power
+// of two): with w[j] = exp(-i pi j^2 / n),
+//     X[k] = w[k] * sum_j (x[j] w[j]) * conj(w)[k - j]
+// i.e. multiply by the chirp, convolve with the conjugate chirp (forward FFT_M, multiply by the chirp's precomputed
+// spectrum, inverse FFT_M, 1/M), multiply by the chirp again.  float64 throughout; the chirp phases are reduced
+// exactly in integers (j^2 mod 2n) before sincospi.  The inverse transform is conj(FFT(conj x)).  This is how
+// pocketfft -- the reference's FFT -- treats lengths with large prime factors too (a 6244 x 4168 sensor gives
+// crops 2084 = 4 * 521 and 3122 = 2 * 7 * 223 long); the O(n^2) direct sum of round 1 is gone.
+
+// `nlines` lines at pitch ld = (C.m ? C.m : n); data in the first n points of each line
 template <bool INV>
-__device__ __forceinline__ void line_fft(cplx *x, cplx *tmp, int n, const cplx *__restrict__ tw, int tid, int nt) {
-    lines_fft<INV>(x, tmp, n, 1, tw, tid, nt);
+__device__ void lines_fft(cplx *base, int n, int nlines, const cplx *__restrict__ tw, const Chirp &C, int tid, int nt) {
+    if (!C.m) {
+        lines_fft_pow2<INV>(base, n, nlines, tw, tid, nt);
+        return;
+    }
+    const int M = C.m;
+    for (int e = tid; e < nlines * M; e += nt) {
+        const int j = e & (M - 1);
+        cplx v = {0.0, 0.0};
+        if (j < n) {
+            v = base[e];
+            if (INV) v.im = -v.im;
+            v = cmul(v, C.w[j]);
+        }
+        base[e] = v;
+    }
+    __syncthreads();
+    lines_fft_pow2<false>(base, M, nlines, C.twm, tid, nt);
+    for (int e = tid; e < nlines * M; e += nt) base[e] = cmul(base[e], C.spec[e & (M - 1)]);
+    __syncthreads();
+    lines_fft_pow2<true>(base, M, nlines, C.twm, tid, nt);
+    const double inv_m = 1.0 / (double)M;
+    for (int e = tid; e < nlines * M; e += nt) {
+        const int j = e & (M - 1);
+        if (j < n) {
+            cplx v = cmul(base[e], C.w[j]);
+            v.re *= inv_m;
+            v.im *= inv_m;
+            if (INV) v.im = -v.im;
+            base[e] = v;
+        }
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,6 +286,22 @@ __global__ void init_tables_kernel(RegParams P) {
         sincospi(-2.0 * (double)k / (double)L.n1, &s, &c);
         tw1[k] = {c, s};
     }
+    for (int axis = 0; axis < 2; ++axis) {   // Bluestein tables of the axes that need them
+        const int n = axis ? L.n1 : L.n0, M = axis ? L.m1 : L.m0;
+        if (!M) continue;
+        cplx *twm = reinterpret_cast<cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
+        cplx *w = reinterpret_cast<cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
+        for (int64_t k = gid; k < M; k += stride) {
+            double sn, cs;
+            sincospi(-2.0 * (double)k / (double)M, &sn, &cs);
+            twm[k] = {cs, sn};
+        }
+        for (int64_t j = gid; j < n; j += stride) {
+            double sn, cs;
+            sincospi(-(double)((j * j) % (2 * (int64_t)n)) / (double)n, &sn, &cs);   // exp(-i pi j^2 / n), phase reduced exactly
+            w[j] = {cs, sn};
+        }
+    }
     const int64_t m0 = (int64_t)L.n0 * L.up, m1 = (int64_t)L.n1 * L.up;
     for (int64_t j = gid; j < m0; j += stride) {
         double s, c;
@@ -235,6 +313,29 @@ __global__ void init_tables_kernel(RegParams P) {
         sincospi(2.0 * (double)j / (double)m1, &s, &c);
         up1[j] = {c, s};
     }
+}
+
+// spectrum of the conjugate chirp, once per axis and launch: block 0 = axis 0, block 1 = axis 1
+__global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout &L = P.L;
+    const int axis = blockIdx.x;
+    const int n = axis ? L.n1 : L.n0, M = axis ? L.m1 : L.m0;
+    if (!M) return;
+    cplx *x = reinterpret_cast<cplx *>(smem);
+    const cplx *w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
+    const cplx *twm = reinterpret_cast<const cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
+    cplx *spec = reinterpret_cast<cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < M; j += nt) {   // conj(w)[m] at m and at M - m, zero between n - 1 and M - n + 1
+        cplx v = {0.0, 0.0};
+        if (j < n) v = cconj(w[j]);
+        else if (M - j < n) v = cconj(w[M - j]);
+        x[j] = v;
+    }
+    __syncthreads();
+    lines_fft_pow2<false>(x, M, 1, twm, tid, nt);
+    for (int j = tid; j < M; j += nt) spec[j] = x[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,8 +427,8 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
-    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][n1]
-    cplx *tmp = x + (int64_t)rl * n1;              // [n1] (direct DFT only)
+    const int ld = L.m1 ? L.m1 : n1;               // line pitch: the Bluestein length when n1 is not a power of two
+    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
     const int pair = blockIdx.y, r0 = blockIdx.x * rl;
     const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
@@ -348,13 +449,13 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
         const int l = e / n1, j = e - l * n1;
         const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
         const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
-        x[e] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+        x[(int64_t)l * ld + j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     }
     __syncthreads();
-    lines_fft<false>(x, tmp, n1, nrow, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    lines_fft<false>(x, n1, nrow, reinterpret_cast<const cplx *>(P.ws + L.tw1), chirp_of(P, 1), tid, nt);
     for (int e = tid; e < nrow * n1h; e += nt) {
         const int l = e / n1h, k = e - l * n1h;
-        const cplx *xl = x + (int64_t)l * n1;
+        const cplx *xl = x + (int64_t)l * ld;
         const cplx zk = xl[k], zc = cconj(xl[k ? n1 - k : 0]);
         // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
         A[e] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
@@ -381,7 +482,6 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     const int n0 = L.n0, n1h = L.n1h, tc = P.tc;
     cplx *f = reinterpret_cast<cplx *>(smem);   // [tc][n0]
     cplx *g = f + (int64_t)tc * n0;             // [tc][n0]
-    cplx *tmp = g + (int64_t)tc * n0;           // [n0] (direct DFT only)
     __shared__ double red[2][SQ_COL_THREADS / 64];
     const int pair = blockIdx.y, c0 = blockIdx.x * tc;
     const int ncol = min(tc, n1h - c0);
@@ -396,10 +496,10 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     __syncthreads();
     const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
-        lines_fft<false>(f, tmp, n0, 2 * tc, tw0, tid, nt);
+        lines_fft_pow2<false>(f, n0, 2 * tc, tw0, tid, nt);
     } else {
-        lines_fft<false>(f, tmp, n0, ncol, tw0, tid, nt);
-        lines_fft<false>(g, tmp, n0, ncol, tw0, tid, nt);
+        lines_fft_pow2<false>(f, n0, ncol, tw0, tid, nt);
+        lines_fft_pow2<false>(g, n0, ncol, tw0, tid, nt);
     }
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
@@ -444,11 +544,73 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
     }
     __syncthreads();
-    lines_fft<true>(f, tmp, n0, ncol, tw0, tid, nt);
+    lines_fft_pow2<true>(f, n0, ncol, tw0, tid, nt);
     for (int i = tid; i < n0 * ncol; i += nt) {
         const int r = i / ncol, c = i - r * ncol;
         A[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
     }
+}
+
+// The same for an axis-0 length that is not a power of two: one column per block, transformed in place in ONE
+// Bluestein line of m0 points (128 KB of LDS at m0 = 8192); the column spectra F and G go back to the workspace
+// between the three transforms instead of staying in LDS -- every thread re-reads exactly the elements it wrote.
+__global__ __launch_bounds__(SQ_COL_THREADS) void columns_bluestein_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout &L = P.L;
+    const int n0 = L.n0, n1h = L.n1h;
+    cplx *x = reinterpret_cast<cplx *>(smem);   // [m0]
+    __shared__ double red[2][SQ_COL_THREADS / 64];
+    const int pair = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
+    cplx *B = A + (int64_t)n0 * n1h;
+    const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
+    const Chirp C = chirp_of(P, 0);
+    for (int r = tid; r < n0; r += nt) x[r] = A[(int64_t)r * n1h];
+    __syncthreads();
+    lines_fft<false>(x, n0, 1, tw0, C, tid, nt);
+    for (int r = tid; r < n0; r += nt) {
+        A[(int64_t)r * n1h] = x[r];            // F, re-read below by this very thread
+        x[r] = B[(int64_t)r * n1h];
+    }
+    __syncthreads();
+    lines_fft<false>(x, n0, 1, tw0, C, tid, nt);
+    const double eps100 = 100.0 * 2.220446049250313e-16;
+    double sf = 0.0, sg = 0.0;
+    for (int r = tid; r < n0; r += nt) {
+        const cplx F = A[(int64_t)r * n1h], G = x[r];
+        sf += F.re * F.re + F.im * F.im;
+        sg += G.re * G.re + G.im * G.im;
+        cplx pr = cmul(F, cconj(G));                              // skimage :211
+        if (P.normalization == SQ_NORM_PHASE) {
+            const double scl = 1.0 / fmax(hypot(pr.re, pr.im), eps100);
+            pr.re *= scl;
+            pr.im *= scl;
+        }
+        B[(int64_t)r * n1h] = pr;              // the product is what the upsampled DFT reads (skimage :239)
+        x[r] = pr;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sf += __shfl_xor(sf, off);
+        sg += __shfl_xor(sg, off);
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = sf;
+        red[1][tid >> 6] = sg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < (nt >> 6); ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c) * 2;
+        amps[0] = a;
+        amps[1] = b;
+    }
+    lines_fft<true>(x, n0, 1, tw0, C, tid, nt);
+    for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -509,8 +671,8 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
     const int nrp = (n0 + 1) / 2;
-    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][n1]
-    cplx *tmp = x + (int64_t)rl * n1;
+    const int ld = L.m1 ? L.m1 : n1;
+    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
     const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
     const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -530,15 +692,15 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
             b = cconj(q1[n1 - k]);
         }
         if (!two) b = {0.0, 0.0};
-        x[e] = {a.re - b.im, a.im + b.re};   // a + i b
+        x[(int64_t)l * ld + k] = {a.re - b.im, a.im + b.re};   // a + i b
     }
     __syncthreads();
-    lines_fft<true>(x, tmp, n1, nline, reinterpret_cast<const cplx *>(P.ws + L.tw1), tid, nt);
+    lines_fft<true>(x, n1, nline, reinterpret_cast<const cplx *>(P.ws + L.tw1), chirp_of(P, 1), tid, nt);
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int l = wave; l < nline; l += nw) {
         const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);
         const bool two = (y0 + 1) < n0;
-        const cplx *xl = x + (int64_t)l * n1;
+        const cplx *xl = x + (int64_t)l * ld;
         Best best = {-1.0, (long long)1 << 62, 0};
         for (int k = lane; k < n1; k += 64) {
             best = better(best, make_best(fabs(xl[k].re), (long long)y0 * n1 + k));
@@ -564,7 +726,7 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
     // the column energies are summed by one thread in column order (a fixed order: the sums are
     // outputs); staging them through LDS first turns its chain of dependent global loads into one
     // coalesced read by the block
-    __shared__ double amp_l[2 * (MAX_POW2 / 2 + 1)];
+    __shared__ double amp_l[2 * (MAX_LINE / 2 + 1)];
     const double *amps = reinterpret_cast<const double *>(P.ws + L.amps) + (int64_t)pair * L.n1h * 2;
     for (int i = tid; i < 2 * L.n1h; i += nt) amp_l[i] = amps[i];
     Best best = {-1.0, (long long)1 << 62, 0};
@@ -775,9 +937,17 @@ __global__ __launch_bounds__(256) void normalize_kernel(const void *const *tile_
 
 int check_line(int n, const char *axis) {
     if (n < 2) return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %s length %d < 2", axis, n);
-    if (is_pow2(n) ? n > MAX_POW2 : n > MAX_DIRECT)
-        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported (power of two <= %d, other <= %d)",
-                    axis, n, MAX_POW2, MAX_DIRECT);
+    if (n > MAX_LINE)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported (any length up to %d: one line, or its "
+                    "Bluestein line of up to %d points, has to fit the 160 KB of LDS)", axis, n, MAX_LINE, MAX_BLUESTEIN_M);
+    return SQ_OK;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return SQ_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: cannot raise the LDS limit to %zu bytes: %s", bytes, hipGetErrorString(e));
     return SQ_OK;
 }
 
@@ -878,20 +1048,24 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.n_tiles = a->n_tiles;
     P.tile_h = a->tile_h;
     P.tile_w = a->tile_w;
-    // columns per block: two [tc][n0] complex arrays (+ one scratch line for the direct DFT) in 144 KiB of LDS
-    const int64_t scratch = is_pow2(L.n0) ? 0 : (int64_t)L.n0 * 16;
-    int tc = (int)std::min<int64_t>(8, (144 * 1024 - scratch) / (2 * (int64_t)L.n0 * 16));
+    // columns per block (power-of-two axis 0): two [tc][n0] complex arrays in 144 KiB of LDS
+    int tc = (int)std::min<int64_t>(8, (144 * 1024) / (2 * (int64_t)L.n0 * 16));
     if (tc < 1) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: axis-0 length %d does not fit LDS", L.n0);
     P.tc = tc;
     hipStream_t s = static_cast<hipStream_t>(stream_);
 
     hipLaunchKernelGGL(init_tables_kernel, dim3(64), dim3(256), 0, s, P);
+    if (L.m0 || L.m1) {   // spectra of the Bluestein chirps, one block per axis
+        const size_t lds_chirp = (size_t)std::max(L.m0, L.m1) * 16;
+        if ((rc = allow_lds(init_chirp_kernel, lds_chirp)) != SQ_OK) return rc;
+        hipLaunchKernelGGL(init_chirp_kernel, dim3(2), dim3(256), lds_chirp, s, P);
+    }
     // Lines per block of the row kernels, measured on 240-pair batches: the forward kernel (global loads
     // + a float64 normalisation per pixel) likes many small blocks -- 16 KB of lines; the inverse kernel
     // (LDS FFT + a per-wave argmax) likes up to 8 lines within 64 KB.  Never more than keeps ~2 blocks
     // per CU busy when the batch is small (the bench's single centre pairs).
-    const int64_t line_bytes = (int64_t)L.n1 * 16;
-    const int64_t dft_scratch = is_pow2(L.n1) ? 0 : line_bytes;
+    const int64_t line_bytes = (int64_t)(L.m1 ? L.m1 : L.n1) * 16;   // a Bluestein line is m1 points long
+    const int64_t dft_scratch = 0;
     auto lines_per_block = [&](int cap, int n_lines) {
         int rl = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (64 * 1024 - dft_scratch) / line_bytes));
         while (rl > 1 && (int64_t)a->n_pairs * ((n_lines + rl - 1) / rl) < 512) rl >>= 1;
@@ -903,17 +1077,23 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.rl_inv = rli;
     const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
     const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
-    if (a->tile_dtype == SQ_U16)
+    if (a->tile_dtype == SQ_U16) {
+        if ((rc = allow_lds(rows_forward_kernel<uint16_t>, lds_fwd)) != SQ_OK) return rc;
         hipLaunchKernelGGL(rows_forward_kernel<uint16_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
-    else
+    } else {
+        if ((rc = allow_lds(rows_forward_kernel<uint8_t>, lds_fwd)) != SQ_OK) return rc;
         hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
-    const size_t lds_col = ((size_t)2 * tc + 1) * L.n0 * 16;
-    if (lds_col > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(columns_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_col);
-        if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_register_pairs: cannot raise LDS limit: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+    if (L.m0) {
+        const size_t lds_col = (size_t)L.m0 * 16;
+        if ((rc = allow_lds(columns_bluestein_kernel, lds_col)) != SQ_OK) return rc;
+        hipLaunchKernelGGL(columns_bluestein_kernel, dim3(L.n1h, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+    } else {
+        const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
+        if ((rc = allow_lds(columns_kernel, lds_col)) != SQ_OK) return rc;
+        hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+    }
+    if ((rc = allow_lds(rows_inverse_kernel, lds_inv)) != SQ_OK) return rc;
     hipLaunchKernelGGL(rows_inverse_kernel, dim3(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs), dim3(nti), lds_inv, s, P);
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {

@@ -17,6 +17,25 @@ import numpy as np
 from . import native, placement
 from .placement import Shifts
 
+MAX_CROP_LENGTH = 4096    # longest crop side sq_register_pairs takes (include/squidstitch.h)
+
+
+def check_crop_lengths(height: int, width: int, max_x_overlap: int, max_y_overlap: int) -> None:
+    """Raise before any work if the registration crops of a ``height x width`` tile are longer than the device
+    pipeline takes.  The reference (pocketfft) has no such limit; this one is a sensor side of ~8192 pixels."""
+    sides = [0]
+    for make, ov in ((placement.horizontal_crop_origins, max_x_overlap), (placement.vertical_crop_origins, max_y_overlap)):
+        try:
+            sides.extend(make(height, width, int(ov))[:2])
+        except ValueError:      # a direction with nothing to register (one row / one column): reported where it is used
+            pass
+    worst = max(sides)
+    if worst > MAX_CROP_LENGTH:
+        raise ValueError(f"registration crops of a {height} x {width} tile are up to {worst} pixels long; the device "
+                         f"pipeline takes crop sides up to {MAX_CROP_LENGTH} (one FFT line has to fit the 160 KB of LDS). "
+                         "Stitch without -r, or supply h_shift / v_shift.")
+
+
 NORMALIZATIONS = {'phase': native.SQ_NORM_PHASE, None: native.SQ_NORM_NONE, 'none': native.SQ_NORM_NONE}
 
 

@@ -100,7 +100,9 @@ def all_gather_shift_table_async(local_rows: np.ndarray, device=None, group=None
     import torch
     import torch.distributed as dist
     local_rows = np.ascontiguousarray(local_rows, dtype=np.int32).reshape(-1, SHIFT_ROW)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and not os.environ.get('SQ_DIST_FORCE_COLLECTIVE')):
         return PendingShiftTable(table=local_rows.copy())
     world = dist.get_world_size(group)
     t = torch.from_numpy(local_rows)

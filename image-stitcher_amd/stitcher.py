@@ -348,6 +348,7 @@ class Stitcher:
             sorted(self.x_positions), sorted(self.y_positions), self.input_width, self.input_height,
             self.pixel_size_um, self.pixel_binning)
         print(f"[registration] crop widths from the stage pitch: {max_x_overlap} px horizontal, {max_y_overlap} px vertical")
+        registration.check_crop_lengths(self.input_height, self.input_width, max_x_overlap, max_y_overlap)
         if getattr(self, 'dynamic_registration', False):
             # --dynamic-registration (parsed but never read by the reference): every adjacent pair of
             # the registration plane, one batch per direction, per-axis median of the integer shifts

@@ -208,7 +208,12 @@ typedef struct sq_register_args {
     int64_t workspace_bytes;
 } sq_register_args;
 
-/* Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
+/* Crop lengths: any n0, n1 in [2, 4096].  A power of two runs as a radix-2 FFT in LDS; every other length runs as
+ * a Bluestein (chirp-z) convolution through a power-of-two LDS FFT of M >= 2n - 1 <= 8192 points, float64 like the
+ * rest -- the way pocketfft (the reference's FFT, via scipy/numpy) treats lengths with large prime factors.  A
+ * longer line does not fit the 160 KB of LDS: SQ_ERR_UNSUPPORTED.  (Crops are about half a tile side long,
+ * stitcher.py:504-506 / :517-519, so this covers sensors up to 8192 pixels a side.)
+ * Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
 

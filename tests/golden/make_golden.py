@@ -190,11 +190,15 @@ def pcc_vectors():
     arrays = {}
     eps = np.finfo(np.float64).eps
     shapes = [(64, 34), (34, 64), (256, 80), (80, 256), (96, 50), (45, 64), (1024, 256), (256, 1024),
-              (63, 33), (50, 47), (64, 34), (33, 128), (128, 127)]   # odd widths; shifts near half the crop (wrap-around)
+              (63, 33), (50, 47), (64, 34), (33, 128), (128, 127),   # odd widths; shifts near half the crop (wrap-around)
+              # lengths with large prime factors (a 6244 x 4168 sensor: crops 2084 = 4 * 521 and 3122 = 2 * 7 * 223
+              # long), a smooth one (1500), 2 * 107, primes (1031, 521), and just past a power of two (2049)
+              (2084, 214), (214, 3122), (1500, 107), (1031, 80), (96, 521), (48, 2049)]
     for i, (n0, n1) in enumerate(shapes):
         seed = 4242 + i
         dy, dx = [(3, -2), (-4, 5), (0, 0), (7, 1), (-1, -6), (2, 2), (5, -3), (-2, 4),
-                  (4, -3), (-5, 6), (12, -11), (-9, 14), (1, -13)][i]
+                  (4, -3), (-5, 6), (12, -11), (-9, 14), (1, -13),
+                  (6, -9), (-7, 11), (13, 3), (-15, -4), (9, 16), (-3, -12)][i]
         big = synth.scene_patch(seed, 100, 100, n0 + 32, n1 + 32)      # 16-px margin: |planted| <= 16
         ref = big[16:16 + n0, 16:16 + n1]
         mov = big[16 - dy:16 - dy + n0, 16 - dx:16 - dx + n1] + synth.noise_patch(seed + 1, n0, n1, 150)

@@ -94,8 +94,8 @@ def test_bad_arguments():
         registration.phase_cross_correlation(a, np.zeros((16, 17), np.uint16))
     with pytest.raises(ValueError, match='normalization'):
         registration.phase_cross_correlation(a, a, normalization='bogus')
-    with pytest.raises(native.NativeError, match='not supported'):
-        registration.phase_cross_correlation(np.zeros((16, 2049), np.uint16), np.zeros((16, 2049), np.uint16))
+    with pytest.raises(native.NativeError, match='not supported'):     # one line (or its Bluestein line) must fit LDS
+        registration.phase_cross_correlation(np.zeros((16, 4097), np.uint16), np.zeros((16, 4097), np.uint16))
 
 
 def test_tile_minmax_and_normalised_crops_via_grid_center():
@@ -159,9 +159,12 @@ def test_config2_crop_shape_1024x256_and_all_pairs_batch():
 
 
 def test_long_non_power_of_two_lines():
-    """3000 x 3000 sensors give 1500-long crops (direct-DFT path, O(n^2)): same shifts as the oracle."""
+    """Any crop length up to 4096 (Bluestein through the power-of-two LDS FFT): 3000 x 3000 sensors give
+    1500-long crops, 6244 x 4168 ones 2084 / 3122, and the longest lines at all (4095, 4096, 2049 = just past a
+    power of two, 3989 prime) on either axis: same shifts as the oracle."""
     rng = np.random.default_rng(4)
-    for n0, n1 in ((1500, 48), (48, 1500), (750, 100)):
+    for n0, n1 in ((1500, 48), (48, 1500), (750, 100), (2084, 214), (218, 3122), (4095, 24), (24, 4095), (4096, 30),
+                   (30, 2049), (3989, 20), (20, 3989), (521, 521)):
         big = synth.scene_patch(77, 0, 0, n0 + 64, n1 + 64)
         dy, dx = 7, -5
         ref = big[32:32 + n0, 32:32 + n1].astype(np.uint16)
