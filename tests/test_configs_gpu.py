@@ -175,3 +175,73 @@ def test_stitch_region_large_planes_distinct_gains_per_channel(tmp_path):
     for c in range(2):
         for z in range(2):
             np.testing.assert_array_equal(got[0, c, z], want[0, c, z], err_msg=f'channel {c} z {z}')
+
+
+def test_config4_full_size_plane_and_25_planes_through_the_work_queues():
+    """BASELINE config 4 at FULL size: one (c, z) plane of the 32x32 grid of 2048^2 tiles (1024 tiles -> a
+    73193 x 58034 canvas, a 303 000-item plan, float32 gains, shifts registered on the device) equals the oracle
+    voxel for voxel -- and the same plan at 25 planes (what one of 8 GPUs fuses: 7.6 M work items through the 32-bit
+    queue arithmetic, plane groups of 5 + partial groups) into a poisoned canvas: every plane is the verified one
+    for its gain image, nothing outside the planes is touched.  The 25 planes read the same tile stack (a pointer
+    table with repeated entries), so the oracle runs twice, not 25 times."""
+    import torch
+    dev = _dev()
+    torch.cuda.empty_cache()
+    g, T = 32, 2048
+    spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=244, ov_x=244, seed=4000)
+    tiles = _device_tiles(spec)                                       # [1024, 2048, 2048], storage order
+    xs = [spec.stage_mm(0, c)[0] for c in range(g)]
+    ys = [spec.stage_mm(r, 0)[1] for r in range(g)]
+    shifts = registration.register_grid_center(tiles, g, g, xs, ys, spec.pixel_size_um, spec.pixel_binning, 'phase')
+    assert (shifts.h_shift, shifts.v_shift) == ((3, -244), (-244, -2))
+    order = placement.filename_order([spec.fov_index(r, c) for r in range(g) for c in range(g)])
+    order_rc = [divmod(i, g) for i in order]
+    rects = placement.grid_rects(g, g, T, T, shifts, order=order_rc)
+    wc, hc = placement.canvas_size(g, g, T, T, use_registration=True, shifts=shifts)
+    # the oracle's own geometry (nothing of placement.py): canvas size and rectangles
+    ow, oh, _ = O.output_dimensions(list(xs), list(ys), T, T, spec.pixel_size_um, True, shifts.h_shift, shifts.v_shift, None, 1)
+    assert (oh, ow) == (hc, wc) == (73193, 58034)
+    want_rects = []
+    for i in order:
+        r, c = divmod(i, g)
+        x_px, y_px, top, bottom, left, right = O.tile_rect({'x': xs[c], 'y': ys[r]}, list(xs), list(ys), T, T, spec.pixel_size_um,
+                                                           True, shifts.h_shift, shifts.v_shift, None, 0, wc, hc)
+        want_rects.append((top, left, T - top - bottom, T - left - right, y_px + top, x_px + left))
+    want_rects = np.array(want_rects, dtype=np.int64)
+    np.testing.assert_array_equal(rects, want_rects)
+    plan = native.FusePlan(rects, T, T, hc, wc)
+    assert plan.n_items > 300000
+    n_planes = 25
+    base = synth.synthetic_flatfield(T, T, np.float32)
+    gains = [base, (base * np.float32(1.03125)).astype(np.float32)]
+    d_gains = [torch.from_numpy(f).to(dev) for f in gains]
+    which = [0] * 13 + [1] * 12
+    canvas = native.empty_canvas(n_planes, hc, wc, torch.uint16, dev)
+    storage = torch.as_strided(canvas, (n_planes * canvas.stride(0),), (1,))
+    storage.view(torch.int16).fill_(-16657)                           # 0xBEEF everywhere, the gaps between planes too
+    esz = T * T * 2
+    ptrs_plane = tiles.data_ptr() + torch.tensor(order, dtype=torch.int64) * esz
+    ptrs = ptrs_plane.repeat(n_planes).to(dev)                        # every plane reads the same 1024 tiles
+    assert n_planes * plan.n_items > 7_000_000
+    native.fuse_planes(plan, None, canvas, [d_gains[k] for k in which], tile_ptrs=ptrs)
+    torch.cuda.synchronize()
+    host = tiles.cpu().numpy()
+    for k, first in ((0, 0), (1, 13)):
+        want = O.fuse_plane_overwrite([host[i] for i in order], want_rects, hc, wc, gains[k])
+        got = canvas[first].cpu().numpy()
+        assert np.array_equal(got, want), f'plane {first} (gain image {k}) differs from the oracle'
+        assert int(np.count_nonzero(want)) <= plan.covered_voxels
+        del want, got
+    ref = {0: canvas[0].view(torch.int16), 1: canvas[13].view(torch.int16)}
+    for p in range(n_planes):
+        assert torch.equal(canvas[p].view(torch.int16), ref[which[p]]), f'plane {p} differs from its verified twin'
+    gap = canvas.stride(0) - hc * wc
+    if gap:
+        pads = torch.as_strided(canvas, (n_planes, gap), (canvas.stride(0), 1), storage_offset=canvas.storage_offset() + hc * wc)
+        assert bool((pads.view(torch.int16) == -16657).all()), "the padding between planes was written"
+    # one plane alone (no plane groups: the per-plane kernel with its queues) gives the same voxels
+    single = native.empty_canvas(1, hc, wc, torch.uint16, dev)
+    native.fuse_planes(plan, None, single, [d_gains[0]], tile_ptrs=ptrs[:g * g])
+    assert torch.equal(single[0].view(torch.int16), ref[0])
+    del canvas, single, tiles
+    torch.cuda.empty_cache()

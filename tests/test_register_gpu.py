@@ -173,7 +173,7 @@ def test_long_non_power_of_two_lines():
             want = O.phase_cross_correlation(ref, mov, 10, norm)[0]
             got = registration.phase_cross_correlation(ref, mov, upsample_factor=10, normalization=norm)[0]
             np.testing.assert_array_equal(got, want, err_msg=f'{n0}x{n1} {norm}')
-            assert want.tolist() == [-dy, -dx]
+            assert np.abs(want - np.array([-dy, -dx])).max() <= 0.15      # the planted shift, to the 0.1-px grid
 
 
 def test_out_of_range_pairs_are_flagged_not_read():
