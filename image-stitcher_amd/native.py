@@ -21,7 +21,7 @@ SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
 SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS = 1, 2, 4
-SQ_VERSION = 101
+SQ_VERSION = 102
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
                        ('dst_y', '<i4'), ('dst_x', '<i4')])
@@ -63,6 +63,10 @@ class _RegisterArgs(C.Structure):
     ]
 
 
+class _BasicInfo(C.Structure):
+    _fields_ = [('reweight_iterations', C.c_int32), ('ladmap_iterations', C.c_int32), ('working_size', C.c_int32)]
+
+
 EXPORTS = {
     'sq_version': (C.c_int, []),
     'sq_last_error': (C.c_char_p, []),
@@ -85,6 +89,9 @@ EXPORTS = {
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_selftest_flat_divide_f64': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
+    'sq_basic_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'sq_basic_fit': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_BasicInfo), C.c_void_p]),
     'sq_synth_tiles': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p]),
 }
@@ -528,6 +535,28 @@ def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_
     """register_pairs_async + fetch: returns a RESULT_DTYPE host array (synchronises)."""
     return register_pairs_async(tiles, minmax, pairs, n0, n1, upsample_factor, normalization, stream,
                                 tile_ptrs, shape, np_dtype).fetch()
+
+
+def basic_fit(tiles, smoothness_flatfield: float = 1.0, stream=None):
+    """Flatfield estimate of a device stack [n, H, W] (uint8 / uint16, n <= 64) -> (device float32 [H, W], info dict).
+    Replaces ``BaSiC(get_darkfield=False, smoothness_flatfield=...).fit(images).flatfield`` (stitcher.py:374-377);
+    parity with basicpy is UNPINNED (the package is absent offline) -- see include/squidstitch.h.  Synchronises."""
+    import torch
+    L = lib()
+    if tiles.dim() != 3 or not tiles.is_cuda or not tiles.is_contiguous():
+        raise ValueError("tiles must be a contiguous [n, H, W] device tensor")
+    n, h, w = (int(v) for v in tiles.shape)
+    need = L.sq_basic_workspace_bytes(n, h, w)
+    if need < 0:
+        raise NativeError(f"sq_basic_workspace_bytes failed: {L.sq_last_error().decode()}")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=tiles.device)
+    out = torch.empty((h, w), dtype=torch.float32, device=tiles.device)
+    info = _BasicInfo()
+    _check(L.sq_basic_fit(None, tiles.data_ptr(), h * w, n, h, w, w, sq_dtype_of(np_dtype_of_torch(tiles.dtype)),
+                          float(smoothness_flatfield), out.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(info),
+                          _stream_ptr(stream)), 'sq_basic_fit')
+    return out, {'reweight_iterations': info.reweight_iterations, 'ladmap_iterations': info.ladmap_iterations,
+                 'working_size': info.working_size}
 
 
 def selftest_flat_divide(exponent: int, n_binades: int, negative: bool, device) -> int:

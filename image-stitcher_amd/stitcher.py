@@ -55,7 +55,7 @@ class Signal:
 class Stitcher:
     def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
                  normalization: Optional[str] = 'phase', zarr_compression: str = 'zlib',
-                 per_region_registration: bool = False):
+                 per_region_registration: bool = False, flatfield_estimator: str = 'auto'):
         self.update_progress = Signal(int, int)
         self.getting_flatfields = Signal()
         self.starting_stitching = Signal()
@@ -85,6 +85,11 @@ class Stitcher:
         if zarr_compression not in ('zlib', 'none'):
             raise ValueError("zarr_compression must be 'zlib' or 'none'")
         self.zarr_compression = zarr_compression
+        if flatfield_estimator not in ('auto', 'basic', 'basicpy', 'mean'):
+            raise ValueError("flatfield_estimator must be 'auto', 'basic', 'basicpy' or 'mean'")
+        self.flatfield_estimator = flatfield_estimator
+        self.flatfield_estimator_used = None      # set by get_flatfields
+        self.flatfield_info = None
         # False: shifts are measured once, on the first timepoint and region, and used everywhere (the
         # reference, stitcher.py:1244-1246).  True: every (timepoint, region) is registered on its own
         # tiles before it is fused (BASELINE config 5: per-well registration).
@@ -448,31 +453,53 @@ class Stitcher:
         return canvas[0].cpu().numpy()
 
     def get_flatfields(self, progress_callback=None):
-        """One gain image per monochrome channel from <= 48 randomly chosen tiles (stitcher.py:365-419).
+        """One gain image per monochrome channel from the reference's sample of tiles -- at most 32 randomly chosen
+        per timepoint, stopping once more than 48 are collected (stitcher.py:365-419).
 
-        The reference fits BaSiC (``basicpy``, a third-party estimator: iterative low-rank / sparse fit on
-        jax) -- when that package is importable the very same call is made here,
-        ``BaSiC(get_darkfield=False, smoothness_flatfield=1).fit(images).flatfield``, so the gains are the
-        reference's.  basicpy and jax are absent offline; without them the estimate is a documented
-        stand-in, NOT a restatement (parity unpinned): per-channel mean of the sampled
-        tiles, box-smoothed, normalised to mean 1.  Either way the estimate is not on the hot path: the
-        divide by the gains is (``apply_flatfield_correction``, in the fusion kernel).  Flatfields already
-        assigned to ``self.flatfields`` are left untouched."""
-        try:
-            from basicpy import BaSiC
-        except Exception:
-            BaSiC = None
-            print("[flatfield] basicpy is not installed: using the mean / box-smooth stand-in estimate "
-                  "(the reference fits BaSiC; assign Stitcher.flatfields to supply your own gains)")
+        The reference fits them with a third-party estimator, ``basicpy.BaSiC(get_darkfield=False,
+        smoothness_flatfield=1).fit(images).flatfield`` (:374-377).  ``flatfield_estimator``:
+          'auto'     basicpy when it is importable (then the very same call is made and the gains are the
+                     reference's), else 'basic';
+          'basic'    the device restatement of the published BaSiC fit (csrc/basic.hip, defined by
+                     oracle/basic_oracle.py).  basicpy and jax are absent offline, so its parity with basicpy is
+                     UNPINNED; it recovers planted gains (tests/test_basic_gpu.py);
+          'basicpy'  basicpy or an ImportError;
+          'mean'     mean of the sample, box-smoothed, mean 1: NOT BaSiC, only on explicit request.
+        Which one ran is kept in ``flatfield_estimator_used`` and written to ``flatfield_info.json`` (and
+        ``shift_table.json``) beside the output.  Either way the estimate is not on the hot path: the divide by the
+        gains is (``apply_flatfield_correction``, in the fusion kernel).  Flatfields already assigned to
+        ``self.flatfields`` are left untouched."""
+        import torch
+        want = self.flatfield_estimator
+        BaSiC = None
+        if want in ('auto', 'basicpy'):
+            try:
+                from basicpy import BaSiC
+            except Exception:
+                if want == 'basicpy':
+                    raise ImportError("flatfield_estimator='basicpy' but basicpy cannot be imported")
+        used = 'basicpy' if BaSiC is not None else ('mean' if want == 'mean' else 'basic')
+        self.flatfield_estimator_used = used
+        self.flatfield_info = {'estimator': used, 'channels': {}}
+        if used == 'basic':
+            print("[flatfield] BaSiC (LADMAP, no darkfield, smoothness 1) on the device: this build's restatement of the "
+                  "published algorithm -- basicpy is not installed, parity with it is unpinned")
+        elif used == 'mean':
+            print("[flatfield] mean / box-smooth estimate on request: this is NOT the reference's BaSiC fit")
 
         def estimate(images: np.ndarray, channel_name: str):
             channel_index = self.monochrome_channels.index(channel_name)
             if channel_index in self.flatfields:
                 return
-            if BaSiC is not None:
+            info = {}
+            if used == 'basicpy':
                 basic = BaSiC(get_darkfield=False, smoothness_flatfield=1)
                 basic.fit(images)
                 self.flatfields[channel_index] = np.asarray(basic.flatfield)
+            elif used == 'basic':
+                stack = torch.from_numpy(np.ascontiguousarray(images)).to(self.device)
+                flat, info = native.basic_fit(stack, 1.0)
+                self.flatfields[channel_index] = flat.cpu().numpy()
             else:
                 acc = images.astype(np.float64).mean(axis=0)
                 k = max(1, min(acc.shape) // 16)
@@ -481,6 +508,7 @@ class Stitcher:
                 n = 2 * k + 1
                 smooth = (csum[n:, n:] - csum[:-n, n:] - csum[n:, :-n] + csum[:-n, :-n]) / (n * n)
                 self.flatfields[channel_index] = (smooth / smooth.mean()).astype(np.float32)
+            self.flatfield_info['channels'][channel_name] = dict(info, images=int(len(images)))
             if progress_callback:
                 progress_callback(channel_index + 1, self.num_c)
 
@@ -508,7 +536,7 @@ class Stitcher:
             elif images.ndim == 4 and images.shape[-1] == 3:    # RGB files: one gain image per colour
                 base = channel.split('_')[0]
                 for i, color in enumerate('RGB'):
-                    estimate(images[..., i], f"{base}_{color}")
+                    estimate(np.ascontiguousarray(images[..., i]), f"{base}_{color}")
             else:
                 raise ValueError(f"Unexpected number of dimensions in images array: {images.ndim}")
 
@@ -835,7 +863,9 @@ class Stitcher:
                 e.update(h_shift_rev=[int(v) for v in s.h_shift_rev], h_shift_rev_odd=int(s.h_shift_rev_odd))
             entries.append(e)
         with open(os.path.join(self.output_folder, 'shift_table.json'), 'w') as fh:
-            json.dump({'per_region_registration': self.per_region_registration, 'shifts': entries}, fh, indent=1)
+            json.dump({'per_region_registration': self.per_region_registration, 'shifts': entries,
+                       'flatfield_estimator': (self.flatfield_info or {}).get('estimator') if self.apply_flatfield else None},
+                      fh, indent=1)
 
     # --------------------------------------------------------------------- run
     # The reference's Stitcher is a QThread: GUIs call start() and listen to the signals.  The same
@@ -877,6 +907,10 @@ class Stitcher:
                 self.get_flatfields(progress_callback=self.update_progress.emit)
                 print("Time to calculate flatfields:", time.time() - stime)
             self.flatfields = sharding.broadcast_object(self.flatfields)   # the estimate samples tiles at random
+            self.flatfield_info = sharding.broadcast_object(self.flatfield_info)
+            if rank == 0 and self.flatfield_info is not None:
+                with open(os.path.join(self.output_folder, 'flatfield_info.json'), 'w') as fh:
+                    json.dump(self.flatfield_info, fh, indent=1)
         coll = sharding.collective_device(self)
         if self.use_registration and not self.per_region_registration:
             if rank == 0:

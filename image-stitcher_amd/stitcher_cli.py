@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Command line of the stitcher: the reference's flags (stitcher_cli.py:14-62) unchanged,
-plus four switches for what this build adds (``--fusion-mode``, ``--normalization``,
-``--zarr-compression``, ``--per-region-registration``).
+plus five switches for what this build adds (``--fusion-mode``, ``--normalization``,
+``--zarr-compression``, ``--per-region-registration``, ``--flatfield-estimator``).
 
     python -m image_stitcher_amd.stitcher_cli -i /path/to/acquisition -r -ff --registration-channel "488"
 """
@@ -34,6 +34,10 @@ FLAGS = (
                                    help="OME-Zarr chunk compressor (none = raw chunks)")),
     (('--per-region-registration',), dict(action='store_true',
                                           help="with -r: register every (timepoint, region) on its own tiles instead of once")),
+    (('--flatfield-estimator',), dict(choices=['auto', 'basic', 'basicpy', 'mean'], default='auto',
+                                      help="with -ff: basicpy's BaSiC fit when that package is installed (auto / basicpy), this "
+                                           "build's device restatement of the published BaSiC fit (basic; what auto falls back "
+                                           "to), or a plain smoothed mean (mean: not BaSiC)")),
 )
 
 
@@ -84,7 +88,8 @@ def main(argv=None):
         stitcher = Stitcher(params, device=device, fusion_mode=args.fusion_mode,
                             normalization=None if args.normalization == 'none' else 'phase',
                             zarr_compression=args.zarr_compression,
-                            per_region_registration=args.per_region_registration)
+                            per_region_registration=args.per_region_registration,
+                            flatfield_estimator=args.flatfield_estimator)
         print("Starting stitching with parameters:")
         for k, v in params.to_dict().items():
             print(f"{k}: {v}")

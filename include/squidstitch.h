@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 101 /* 0.1.1: sq_fuse_args grew flags / grid_blocks */
+#define SQ_VERSION 102 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -216,6 +216,27 @@ typedef struct sq_register_args {
  * Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flatfield ESTIMATE: replaces basicpy.BaSiC(get_darkfield=False, smoothness_flatfield=s).fit(images).flatfield
+ * in Stitcher.get_flatfields (stitcher.py:365-419; the call is :374-377) for one channel's sample of tiles
+ * (<= 64: the reference collects at most 32 per timepoint and stops above 48, :381-395).
+ * PARITY UNPINNED: basicpy is an absent, un-pinned third-party package; this is the published BaSiC algorithm
+ * (Peng et al. 2017; LADMAP + re-weighted L1, no darkfield, basicpy's documented defaults) as defined by
+ * oracle/basic_oracle.py.  Not on the hot path (the divide by the result is: sq_fuse_planes).
+ * Unlike the other entry points this one SYNCHRONISES `stream` (its iteration count is decided by the data).
+ * flatfield_dev: tile_h x tile_w float32, dense.  workspace: sq_basic_workspace_bytes(), 256-byte aligned.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sq_basic_info {
+    int32_t reweight_iterations; /* outer re-weighted-L1 rounds run (<= 10)          */
+    int32_t ladmap_iterations;   /* inner iterations summed over the rounds          */
+    int32_t working_size;        /* 128: the images are resampled to this before the fit */
+} sq_basic_info;
+
+int64_t sq_basic_workspace_bytes(int32_t n_images, int32_t tile_h, int32_t tile_w);
+int sq_basic_fit(const void *const *tile_ptrs_dev, const void *tile_base_dev, int64_t tile_stride, int32_t n_images,
+                 int32_t tile_h, int32_t tile_w, int32_t tile_pitch, int32_t tile_dtype, float smoothness_flatfield,
+                 float *flatfield_dev, void *workspace_dev, int64_t workspace_bytes, sq_basic_info *info, void *stream);
 
 /* Self-test (tests only): the fusion kernels divide uint16 pixels by float32 gains with a shortened
  * sequence that is exact for gains with 2^-100 <= |g| < 2^100.  This compares its

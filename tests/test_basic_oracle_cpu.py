@@ -1,0 +1,49 @@
+"""The CPU definition of the flatfield estimate (oracle/basic_oracle.py: the published BaSiC fit restated; parity
+with basicpy UNPINNED, the package is absent offline) recovers a planted smooth gain from sparse-foreground tiles."""
+import numpy as np
+
+from image_stitcher_amd import synth
+from oracle import basic_oracle as B
+
+
+def planted_stack(n, h, w, seed, noise=20.0, objects=30):
+    """n tiles: a flat background (different level per tile) with a few bright blobs, multiplied by a smooth gain."""
+    rng = np.random.default_rng(seed)
+    gain = synth.synthetic_flatfield(h, w, np.float32)
+    gain = gain / gain.mean()
+    yy, xx = np.ogrid[:h, :w]
+    out = []
+    for _ in range(n):
+        img = np.full((h, w), 3000.0 + 300.0 * rng.random(), dtype=np.float32)
+        for _ in range(objects):
+            y, x, r = rng.integers(0, h), rng.integers(0, w), rng.integers(3, 10)
+            img += 4000.0 * np.exp(-((yy - y) ** 2 + (xx - x) ** 2) / (2.0 * r * r)).astype(np.float32)
+        out.append(img * gain + rng.normal(0.0, noise, (h, w)))
+    return np.clip(np.array(out), 0, 65535).astype(np.uint16), gain
+
+
+def test_resize_matrix_rows_sum_to_one_and_interpolate():
+    for n_out, n_in in ((128, 2048), (128, 300), (300, 128), (7, 7), (128, 100)):
+        m = B.resize_matrix(n_out, n_in)
+        assert m.shape == (n_out, n_in) and np.allclose(m.sum(axis=1), 1.0, atol=1e-6) and (m >= 0).all()
+    ramp = np.arange(64, dtype=np.float32)[None, :].repeat(8, 0)
+    up = B.resize(ramp, 8, 128)
+    assert np.all(np.diff(up[0]) >= -1e-5) and abs(up[0, 64] - 31.75) < 0.51       # a ramp stays a ramp
+    assert np.allclose(B.resize(np.full((1, 300, 200), 5.0, np.float32), 128, 128), 5.0, atol=1e-4)
+
+
+def test_dct_matrix_is_orthonormal():
+    c = B.dct_matrix(128).astype(np.float64)
+    assert np.allclose(c @ c.T, np.eye(128), atol=1e-6)
+
+
+def test_planted_gain_is_recovered():
+    stack, gain = planted_stack(40, 256, 320, seed=5)
+    flat, info = B.basic_fit(stack)
+    assert flat.shape == (256, 320) and flat.dtype == np.float32
+    assert 1 <= len(info['ladmap_iterations']) <= B.MAX_REWEIGHT_ITERATIONS
+    err = np.abs(flat / flat.mean() / gain - 1.0)
+    assert err.mean() < 2e-3 and np.quantile(err, 0.999) < 1e-2, (err.mean(), err.max())
+    # a flat stack gives a flat gain
+    flat2, _ = B.basic_fit(np.full((8, 64, 64), 1234, np.uint16))
+    assert np.allclose(flat2, 1.0, atol=1e-4)

@@ -211,10 +211,11 @@ def test_grid_rects_vectorised_equals_per_tile_formula():
                 np.testing.assert_array_equal(placement.grid_rects(n_rows, n_cols, w, h, sh, od, crop), want.reshape(-1, 6))
 
 
-def test_get_flatfields_standin_and_basicpy_delegation(tmp_path, monkeypatch):
-    """Flatfield *estimation* (stitcher.py:365-419) is host-side and off the hot path: with basicpy present
-    the reference's own call is made; without it a stand-in estimate is used.  uint8 acquisition with an RGB
-    channel: one gain image per monochrome channel."""
+def test_get_flatfields_estimators_and_basicpy_delegation(tmp_path, monkeypatch):
+    """Flatfield *estimation* (stitcher.py:365-419): with basicpy present the reference's own call is made; without
+    it the device restatement of BaSiC runs -- which needs the GPU, so on a CPU-only box it fails LOUDLY instead of
+    silently dividing by something else; the smoothed mean exists only on explicit request.  uint8 acquisition with
+    an RGB channel: one gain image per monochrome channel."""
     import sys
     import types
     from image_stitcher_amd.stitcher import Stitcher
@@ -223,15 +224,24 @@ def test_get_flatfields_standin_and_basicpy_delegation(tmp_path, monkeypatch):
     root = str(tmp_path / 'acq')
     synth.write_acquisition(spec, root)
 
-    def prepared():
-        st = Stitcher(StitchingParameters(input_folder=root, apply_flatfield=True))
+    def prepared(**kw):
+        st = Stitcher(StitchingParameters(input_folder=root, apply_flatfield=True), **kw)
         st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
         return st
 
-    monkeypatch.setitem(sys.modules, 'basicpy', None)            # import fails -> stand-in
-    st = prepared()
+    import torch
+    monkeypatch.setitem(sys.modules, 'basicpy', None)            # import fails
+    with pytest.raises(ImportError):
+        prepared(flatfield_estimator='basicpy').get_flatfields()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no CPU path'):   # 'auto' -> the device BaSiC: no silent stand-in
+            prepared().get_flatfields()
+    with pytest.raises(ValueError):
+        prepared(flatfield_estimator='bogus')
+    st = prepared(flatfield_estimator='mean')                    # explicit request only
     seen = []
     st.get_flatfields(progress_callback=lambda i, n: seen.append((i, n)))
+    assert st.flatfield_estimator_used == 'mean' and st.flatfield_info['estimator'] == 'mean'
     assert sorted(st.flatfields) == list(range(st.num_c)) == [0, 1, 2, 3] and len(seen) == 4
     for ff in st.flatfields.values():
         assert ff.shape == (32, 48) and ff.dtype == np.float32 and abs(float(ff.mean()) - 1.0) < 1e-5
@@ -250,6 +260,7 @@ def test_get_flatfields_standin_and_basicpy_delegation(tmp_path, monkeypatch):
     st = prepared()
     st.flatfields[3] = np.ones((32, 48), np.float32)             # supplied by the caller: left alone
     st.get_flatfields()
+    assert st.flatfield_estimator_used == 'basicpy'
     assert calls == [dict(get_darkfield=False, smoothness_flatfield=1)] * 3
     assert all(float(st.flatfields[i][0, 0]) == 1.25 for i in range(3)) and float(st.flatfields[3][0, 0]) == 1.0
 
