@@ -110,23 +110,32 @@ def create_store(path: str, shape: Sequence[int], dtype, *, pixel_size_um: float
     return shapes
 
 
-def chunk_jobs(levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1, 1, 1, 512, 512)) -> list:
+def chunk_jobs(levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1, 1, 1, 512, 512), row_offset: int = 0,
+               level_heights: Optional[Sequence[int]] = None) -> list:
     """One job per chunk of whole (t, c, z) planes: ``levels[l][i]`` is the 2-D plane ``coords[i]`` at
     pyramid level l.  Chunks never span planes (chunk shape (1,1,1,cy,cx)), so different processes can
-    write different planes of one store concurrently."""
+    write different planes of one store concurrently.
+
+    ``row_offset`` > 0: the arrays are one ROW BAND of the planes, starting at that level-0 row (sharding.row_bands:
+    a multiple of chunk rows x 2^(levels-1), so the band starts on a chunk-row boundary of every level);
+    ``level_heights`` are then the heights of the FULL levels (the chunk height of a level is min(512, its height))."""
     if tuple(chunks[:3]) != (1, 1, 1):
         raise ValueError("plane-wise writing needs chunks of shape (1, 1, 1, cy, cx)")
     jobs = []
     for lv, arr in enumerate(levels):
         if arr.ndim != 3 or len(arr) < len(coords):
             raise ValueError(f"level {lv}: expected [n_planes, y, x] with n_planes >= {len(coords)}, got {arr.shape}")
-        cy, cx = min(chunks[3], arr.shape[1]), min(chunks[4], arr.shape[2])
+        full_h = arr.shape[1] if level_heights is None else int(level_heights[lv])
+        cy, cx = min(chunks[3], full_h), min(chunks[4], arr.shape[2])
         if cy == 0 or cx == 0:
             continue
+        y_off = int(row_offset) >> lv
+        if y_off % cy:
+            raise ValueError(f"row band at level-0 row {row_offset} does not start on a chunk row of level {lv}")
         for i, (t, c, z) in enumerate(coords):
             for y in range(0, arr.shape[1], cy):
                 for x in range(0, arr.shape[2], cx):
-                    jobs.append((lv, t, c, z, y // cy, x // cx, arr[i], y, x, cy, cx))
+                    jobs.append((lv, t, c, z, (y_off + y) // cy, x // cx, arr[i], y, x, cy, cx))
     return jobs
 
 
@@ -150,11 +159,12 @@ def emit_chunk(path: str, job, compression: str = 'zlib', level: int = 1) -> int
 
 
 def write_plane_levels(path: str, levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1, 1, 1, 512, 512),
-                       compression: str = 'zlib', level: int = 1, workers: Optional[int] = None, pool=None) -> int:
-    """Write the chunks of whole planes, every pyramid level given (see ``chunk_jobs``), into a store
-    made by ``create_store``.  Returns the bytes written."""
+                       compression: str = 'zlib', level: int = 1, workers: Optional[int] = None, pool=None,
+                       row_offset: int = 0, level_heights: Optional[Sequence[int]] = None) -> int:
+    """Write the chunks of whole planes (or of one row band of them), every pyramid level given (see
+    ``chunk_jobs``), into a store made by ``create_store``.  Returns the bytes written."""
     from concurrent.futures import ThreadPoolExecutor
-    jobs = chunk_jobs(levels, coords, chunks)
+    jobs = chunk_jobs(levels, coords, chunks, row_offset, level_heights)
     if pool is not None:
         return sum(pool.map(lambda j: emit_chunk(path, j, compression, level), jobs))
     n = workers if workers is not None else min(32, os.cpu_count() or 4)
@@ -224,7 +234,7 @@ class PlaneStreamWriter:
 
     def __init__(self, path: str, shapes: Sequence[tuple], dtype, *, chunks=(1, 1, 1, 512, 512), batch: int = 1,
                  compression: str = 'zlib', level: int = 1, device='cuda:0', workers: Optional[int] = None, slots: int = 2,
-                 buffers=None):
+                 buffers=None, row_offset: int = 0, level_heights: Optional[Sequence[int]] = None):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -232,6 +242,8 @@ class PlaneStreamWriter:
         from . import native
         self.path, self.chunks, self.compression, self.level = path, tuple(chunks), compression, level
         self.batch = int(batch)
+        # a writer of one row band: ``shapes`` are the band's level shapes, chunks land ``row_offset`` level-0 rows down
+        self.row_offset, self.level_heights = int(row_offset), (None if level_heights is None else list(level_heights))
         self.bytes_written = 0
         tdtype = native.torch_dtype_of(np.dtype(dtype).type)
         yx = [tuple(s[3:]) for s in shapes]
@@ -272,7 +284,8 @@ class PlaneStreamWriter:
                 event.synchronize()
                 levels = [h.numpy() for h in self._host[slot]]
                 self.bytes_written += write_plane_levels(self.path, levels, coords, self.chunks, self.compression,
-                                                         self.level, pool=self._pool)
+                                                         self.level, pool=self._pool, row_offset=self.row_offset,
+                                                         level_heights=self.level_heights)
             except BaseException as exc:   # surfaced by the next acquire() / close()
                 self._error = exc
             finally:

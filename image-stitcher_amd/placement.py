@@ -173,6 +173,16 @@ def filename_order(fovs: Sequence[int]) -> List[int]:
     return sorted(range(len(fovs)), key=lambda i: f"{fovs[i]}_")
 
 
+def clip_rect_to_rows(rect, y0: int, y1: int):
+    """A tile rectangle (src_y0, src_x0, h, w, dst_y, dst_x) cut to the canvas rows [y0, y1) and re-based to row y0
+    (the canvas of one row band, sharding.row_bands) -- or None when the tile does not reach into the band."""
+    sy, sx, h, w, dy, dx = (int(v) for v in rect)
+    top, bottom = max(dy, int(y0)), min(dy + h, int(y1))
+    if bottom <= top or w <= 0:
+        return None
+    return (sy + (top - dy), sx, bottom - top, w, top - int(y0), dx)
+
+
 def check_rect_fits_like_numpy(rect, canvas_h: int, canvas_w: int) -> None:
     """The reference clips a tile to the canvas with ``tile[:y_end - y, :x_end - x]`` (stitcher.py:589-598).  When a
     tile starts beyond the canvas edge the slice end is negative, python counts it from the tile's other end,

@@ -57,6 +57,26 @@ def block_cyclic(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+def row_bands(canvas_h: int, num_levels: int, chunk_rows: int = 512) -> List[Tuple[int, int]]:
+    """Level-0 row bands [y0, y1) that ONE (channel, z) plane can be cut into so that several ranks fuse and write it
+    at once (the finest grain; precedent: the reference's per-FOV writers into one pre-created array,
+    zarr_stitcher.py:395-440).  A band is ``chunk_rows * 2^(num_levels - 1)`` rows: it then starts on a chunk-row
+    boundary of EVERY pyramid level (level l halves the rows l times, Scaler.nearest: row y of level l+1 is row 2y+1 of
+    level l), so a rank computes and writes all levels of its bands without touching another rank's chunks.  A canvas
+    shorter than one such band is a single band."""
+    band = int(chunk_rows) << max(0, int(num_levels) - 1)
+    return [(y0, min(y0 + band, int(canvas_h))) for y0 in range(0, max(1, int(canvas_h)), band)]
+
+
+def plane_band_units(n_planes: int, bands: Sequence[Tuple[int, int]], rank: int, world: int) -> List[Tuple[int, int]]:
+    """(plane, band index) work units of rank ``rank``: planes first when there are enough of them (whole planes,
+    no tile is read twice), else every plane cut into its bands -- dealt block-cyclically either way."""
+    if n_planes >= world or len(bands) <= 1:
+        return [(p, -1) for p in block_cyclic(n_planes, rank, world)]      # -1: the whole plane
+    units = [(p, b) for p in range(n_planes) for b in range(len(bands))]
+    return [units[i] for i in block_cyclic(len(units), rank, world)]
+
+
 def shifts_to_row(s: Optional[Shifts]) -> np.ndarray:
     row = np.zeros(SHIFT_ROW, dtype=np.int32)
     if s is None:

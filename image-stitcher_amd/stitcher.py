@@ -588,14 +588,17 @@ class Stitcher:
             return planes.unflatten(0, (self.num_c, self.num_z)).unsqueeze(0)
         return native.planes_to_host(planes).reshape(shape)
 
-    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None):
+    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None, row_band=None):
         """Fuse the (channel, z) planes ``only_planes`` (plane = channel * num_z + z; None = all) of one
         (timepoint, region) -> (device tensor [n, Hc, Wc], sorted plane ids).  Planes are independent,
         which is what lets several GPUs share one region.
 
         ``stream_to``: callable ``batch -> omezarr.PlaneStreamWriter``.  When given, no region-sized canvas
         is allocated: every batch of planes is fused into one of the writer's two slots and leaves
-        for disk while the next batch is read and fused; the return value is (None, plane ids)."""
+        for disk while the next batch is read and fused; the return value is (None, plane ids).
+
+        ``row_band`` = (y0, y1): only these canvas rows of the planes (sharding.row_bands -- one plane shared by
+        several GPUs); the canvas is then y1 - y0 rows high, tiles outside the band are not even read."""
         import torch
         start_time = time.time()
         region_data = self.get_region_data(int(timepoint), region)
@@ -610,7 +613,12 @@ class Stitcher:
         # dense rows like the reference's array, every plane on a 128-byte line (native.empty_canvas)
         flat_canvas = None if stream_to is not None else \
             native.empty_canvas(len(plane_ids), height, width, native.torch_dtype_of(self.dtype), self.device)
-        hc, wc = height, width
+        y0, y1 = (0, height) if row_band is None else (int(row_band[0]), int(row_band[1]))
+        if not (0 <= y0 < y1 <= height):
+            raise ValueError(f"row band {row_band} outside the {height}-row canvas")
+        hc, wc = y1 - y0, width
+        if flat_canvas is not None and row_band is not None:
+            flat_canvas = native.empty_canvas(len(plane_ids), hc, wc, native.torch_dtype_of(self.dtype), self.device)
         th, tw = self.input_height, self.input_width
         total_tiles = len(region_data)
         print(f"Beginning stitching of {total_tiles} tiles for region {region} timepoint {timepoint}")
@@ -621,6 +629,10 @@ class Stitcher:
             _, _, fov, z_level, channel = key
             rect = self._tile_rect(info)
             placement.check_rect_fits_like_numpy(rect, height, width)
+            if row_band is not None:
+                rect = placement.clip_rect_to_rows(rect, y0, y1)
+                if rect is None:
+                    continue
             if channel in self.monochrome_channels:
                 targets = [(self.monochrome_channels.index(channel) * self.num_z + z_level, -1)]
             else:   # RGB file -> three monochrome channels (stitcher.py:551-556)
@@ -769,7 +781,8 @@ class Stitcher:
                                       name=f"{region}_t{timepoint}", compression=self.zarr_compression)
         return output_path, shapes
 
-    def stream_region_to_zarr(self, timepoint, region, only_planes=None, progress_callback=None, create: bool = True):
+    def stream_region_to_zarr(self, timepoint, region, only_planes=None, progress_callback=None, create: bool = True,
+                              row_band=None):
         """stitch_region + save_region_ome_zarr without the region ever existing in one piece: planes
         are fused a batch at a time and stream through pyramid kernel, pinned D2H copy and compression
         threads while the next batch is read and fused.  Same store as
@@ -781,31 +794,50 @@ class Stitcher:
             width, height = self.calculate_output_dimensions(timepoint, region)
             shapes = omezarr.level_shapes((1, self.num_c, self.num_z, height, width), self.num_pyramid_levels)
         made = []
+        row_offset, level_heights = 0, None
+        if row_band is not None:       # this call writes one row band of the planes: its own (smaller) level buffers
+            level_heights = [s[3] for s in shapes]
+            row_offset = int(row_band[0])
+            shapes = omezarr.level_shapes((1, self.num_c, self.num_z, int(row_band[1]) - row_offset, shapes[0][4]), len(shapes))
+            if len(shapes) != len(level_heights):
+                raise ValueError(f"row band {row_band} is too short for {len(level_heights)} pyramid levels")
 
         def make_writer(batch):
             key = ('writer', tuple(tuple(s[3:]) for s in shapes), batch, np.dtype(self.dtype).str)
             made.append(omezarr.PlaneStreamWriter(output_path, shapes, self.dtype, chunks=self.chunks or (1, 1, 1, 512, 512),
                                                   batch=batch, compression=self.zarr_compression, device=self.device,
-                                                  buffers=self._buffer_cache.get(key)))
+                                                  buffers=self._buffer_cache.get(key), row_offset=row_offset,
+                                                  level_heights=level_heights))
             self._keep_buffers(key, made[-1].buffers)
             return made[-1]
 
-        _, ids = self.stitch_planes(timepoint, region, only_planes, progress_callback, stream_to=make_writer)
+        _, ids = self.stitch_planes(timepoint, region, only_planes, progress_callback, stream_to=make_writer, row_band=row_band)
         self.last_bytes_written = sum(w.bytes_written for w in made)
         return output_path
 
     def _run_region_by_planes(self, timepoint, region, rank, world):
-        """One region shared by all ranks: plane p goes to rank p % world.  Chunks of
-        an OME-Zarr store never span planes, so the ranks write into one store without locking."""
-        mine = sharding.block_cyclic(self.num_c * self.num_z, rank, world)
-        print(f"\nProcessing timepoint {timepoint}, region {region}: planes {mine} (rank {rank}/{world})")
+        """One region shared by all ranks.  With at least as many (channel, z) planes as ranks, plane
+        p goes to rank p % world; with fewer, every plane is cut into row bands of 512 * 2^(levels-1) level-0 rows
+        (sharding.row_bands: whole chunk rows at every pyramid level) and the (plane, band) units are dealt instead
+        -- a rank then reads only the tiles that reach into its bands.  Chunks of an OME-Zarr store span neither
+        planes nor bands, so the ranks write into one store without locking."""
+        n_planes = self.num_c * self.num_z
+        width, height = self.calculate_output_dimensions(timepoint, region)
+        bands = sharding.row_bands(height, self.num_pyramid_levels, (self.chunks or (1, 1, 1, 512, 512))[3])
+        units = sharding.plane_band_units(n_planes, bands, rank, world)
+        print(f"\nProcessing timepoint {timepoint}, region {region}: (plane, band) units {units} (rank {rank}/{world})")
         if rank == 0:
             self.create_region_store(timepoint, region)
         sharding.barrier()
         self.starting_stitching.emit()
         self.starting_saving.emit(False)
-        output_path = self.stream_region_to_zarr(timepoint, region, mine, progress_callback=self.update_progress.emit,
-                                                 create=False)
+        output_path = self._zarr_path(timepoint, region)
+        by_band = {}
+        for p, b in units:
+            by_band.setdefault(b, []).append(p)
+        for b, planes in by_band.items():
+            output_path = self.stream_region_to_zarr(timepoint, region, planes, progress_callback=self.update_progress.emit,
+                                                     create=False, row_band=None if b < 0 else bands[b])
         sharding.barrier()
         return output_path
 
@@ -864,7 +896,8 @@ class Stitcher:
             entries.append(e)
         with open(os.path.join(self.output_folder, 'shift_table.json'), 'w') as fh:
             json.dump({'per_region_registration': self.per_region_registration, 'shifts': entries,
-                       'flatfield_estimator': (self.flatfield_info or {}).get('estimator') if self.apply_flatfield else None},
+                       'flatfield_estimator': (getattr(self, 'flatfield_info', None) or {}).get('estimator')
+                       if getattr(self, 'apply_flatfield', False) else None},
                       fh, indent=1)
 
     # --------------------------------------------------------------------- run

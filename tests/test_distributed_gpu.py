@@ -99,3 +99,41 @@ def _worker_planes(rank, world, port, root, channel, per_region=False):
                        '--normalization', 'none'] + (['--per-region-registration'] if per_region else []))
     import torch.distributed as dist
     dist.destroy_process_group()
+
+
+def _worker_bands(rank, world, port, root):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SQ_DIST_BACKEND='gloo')
+    from image_stitcher_amd import stitcher_cli
+    stitcher_cli.main(['-i', root, '-r', '--normalization', 'none', '--zarr-compression', 'none'])
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_one_plane_split_across_ranks_by_chunk_rows(tmp_path, world):
+    """SURVEY 8e, the finest grain: ONE (channel, z) plane and more GPUs than planes.  The 4343-row canvas of the golden
+    2x2 grid of 2048^2 tiles has 3 pyramid levels, so it is cut into bands of 512 * 4 = 2048 level-0 rows (3 bands);
+    the ranks fuse their bands (reading only the tiles that reach into them) and write the chunks of ALL levels of
+    their bands into the one store.  Level 0 equals the reference's canvas, the pyramid the oracle's."""
+    import torch.multiprocessing as mp
+    from oracle import stitch_oracle as O
+    info, arrays = load_case('reg_2x2_2048')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_bands, args=(world, port, root), nprocs=world, join=True)
+    outs = [d for d in os.listdir(tmp_path) if d.startswith('acq_stitched_')]
+    assert len(outs) == 1
+    store = os.path.join(tmp_path, outs[0], '0_stitched', 'R0_stitched.ome.zarr')
+    cinfo = info['canvases']['t0_R0']
+    level0 = omezarr.read_array(os.path.join(store, '0'))
+    assert list(level0.shape) == cinfo['shape'] and cinfo['num_pyramid_levels'] == 3
+    from helpers import sha
+    assert sha(level0) == cinfo['sha256']
+    for lv, want in enumerate(O.pyramid_nearest(level0, 3)):
+        np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, str(lv))), want)
+    # chunk rows 0-3, 4-7 and 8 of level 0 came from different bands: every chunk file of the canvas is there
+    rows = sorted(int(d) for d in os.listdir(os.path.join(store, '0', '0', '0', '0')))
+    assert rows == list(range(9))

@@ -286,3 +286,34 @@ def test_degenerate_grids_behave_like_the_reference(tmp_path, rows, cols):
         st.calculate_shifts(0, 'R0')
     with pytest.raises(IndexError):
         O.calculate_shifts(acq, 0, 'R0', read_image, '', 0, 'Unidirectional', 'phase')
+
+
+def test_row_bands_and_plane_band_units():
+    from image_stitcher_amd import omezarr, sharding
+    assert sharding.row_bands(4343, 3) == [(0, 2048), (2048, 4096), (4096, 4343)]
+    assert sharding.row_bands(4343, 1) == [(i, min(i + 512, 4343)) for i in range(0, 4343, 512)]
+    assert sharding.row_bands(300, 2) == [(0, 300)] and sharding.row_bands(1, 5) == [(0, 1)]
+    for h, levels in ((4343, 3), (36473, 6), (73193, 7), (512, 1), (513, 1)):
+        bands = sharding.row_bands(h, levels)
+        assert bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+        for y0, _ in bands:
+            for lv in range(levels):      # a band starts on a chunk row of every level
+                assert (y0 >> lv) % min(512, max(1, h >> lv)) == 0
+    # enough planes: whole planes; fewer planes than ranks: (plane, band) units, each exactly once
+    assert sharding.plane_band_units(4, [(0, 10), (10, 20)], 1, 2) == [(1, -1), (3, -1)]
+    seen = sorted(u for r in range(3) for u in sharding.plane_band_units(1, [(0, 1), (1, 2), (2, 3), (3, 4)], r, 3))
+    assert seen == [(0, b) for b in range(4)]
+    assert sharding.plane_band_units(1, [(0, 9)], 0, 4) == [(0, -1)] and sharding.plane_band_units(1, [(0, 9)], 1, 4) == []
+    # rectangles cut to a band
+    assert placement.clip_rect_to_rows((10, 5, 100, 50, 200, 7), 0, 250) == (10, 5, 50, 50, 200, 7)
+    assert placement.clip_rect_to_rows((10, 5, 100, 50, 200, 7), 250, 400) == (60, 5, 50, 50, 0, 7)
+    assert placement.clip_rect_to_rows((10, 5, 100, 50, 200, 7), 220, 260) == (30, 5, 40, 50, 0, 7)
+    assert placement.clip_rect_to_rows((10, 5, 100, 50, 200, 7), 300, 400) is None
+    assert placement.clip_rect_to_rows((10, 5, 100, 50, 200, 7), 0, 200) is None
+    # the chunk jobs of a band land on the chunk rows of the full levels
+    full = [np.arange(1100 * 600, dtype=np.uint16).reshape(1, 1100, 600), np.zeros((1, 550, 300), np.uint16)]
+    band = [full[0][:, 1024:], full[1][:, 512:]]
+    jobs = omezarr.chunk_jobs(band, [(0, 0, 0)], (1, 1, 1, 512, 512), row_offset=1024, level_heights=[1100, 550])
+    assert sorted((j[0], j[4], j[5]) for j in jobs) == [(0, 2, 0), (0, 2, 1), (1, 1, 0)]
+    with pytest.raises(ValueError):
+        omezarr.chunk_jobs(band, [(0, 0, 0)], (1, 1, 1, 512, 512), row_offset=1000, level_heights=[1100, 550])
