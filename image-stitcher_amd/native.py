@@ -89,6 +89,11 @@ EXPORTS = {
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_selftest_flat_divide_f64': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
     'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
+    'sq_blosc_chunk_count': (C.c_int64, [C.c_int32] * 5),
+    'sq_blosc_out_bound': (C.c_int64, [C.c_int32] * 6),
+    'sq_blosc_scratch_bytes': (C.c_int64, [C.c_int32] * 6),
+    'sq_blosc_encode_planes': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'sq_basic_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'sq_basic_fit': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_BasicInfo), C.c_void_p]),
@@ -535,6 +540,44 @@ def register_pairs(tiles, minmax, pairs: np.ndarray, n0: int, n1: int, upsample_
     """register_pairs_async + fetch: returns a RESULT_DTYPE host array (synchronises)."""
     return register_pairs_async(tiles, minmax, pairs, n0, n1, upsample_factor, normalization, stream,
                                 tile_ptrs, shape, np_dtype).fetch()
+
+
+class BloscBuffers:
+    """Device buffers of one sq_blosc_encode_planes geometry: scratch, chunk offsets, packed frames, status."""
+
+    def __init__(self, n_planes: int, h: int, w: int, np_dtype, chunk_h: int, chunk_w: int, device):
+        import torch
+        L = lib()
+        dt = sq_dtype_of(np_dtype)
+        self.geometry = (int(n_planes), int(h), int(w), dt, int(chunk_h), int(chunk_w))
+        self.n_chunks = int(L.sq_blosc_chunk_count(n_planes, h, w, chunk_h, chunk_w))
+        self.bound = int(L.sq_blosc_out_bound(*self.geometry))
+        need = int(L.sq_blosc_scratch_bytes(*self.geometry))
+        if min(self.n_chunks, self.bound, need) < 0:
+            raise NativeError(f"sq_blosc geometry: {L.sq_last_error().decode()}")
+        self.scratch = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        self.offsets = torch.empty(self.n_chunks + 1, dtype=torch.int64, device=device)
+        self.out = torch.empty(max(self.bound, 1), dtype=torch.uint8, device=device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def blosc_encode_planes(planes, chunk_h: int, chunk_w: int, buffers: Optional[BloscBuffers] = None, stream=None) -> BloscBuffers:
+    """Enqueue the Blosc-1 (shuffle + LZ4) encoding of the chunks of ``planes`` [n, H, W] (uint8 / uint16 device tensor,
+    unit-stride rows, any pitch / plane stride).  Returns the buffers: after the stream has run, chunk i (plane-major,
+    chunk row, chunk column) is ``buffers.out[offsets[i]:offsets[i + 1]]`` with ``offsets = buffers.offsets``
+    (size 0 = all-zero chunk).  Nothing is synchronised or copied here."""
+    L = lib()
+    if planes.dim() != 3 or not planes.is_cuda or (planes.shape[2] > 1 and planes.stride(2) != 1):
+        raise ValueError("planes must be a [n, H, W] device tensor with unit-stride rows")
+    n, h, w = (int(v) for v in planes.shape)
+    npdt = np_dtype_of_torch(planes.dtype)
+    if buffers is None or buffers.geometry != (n, h, w, sq_dtype_of(npdt), int(chunk_h), int(chunk_w)):
+        buffers = BloscBuffers(n, h, w, npdt, chunk_h, chunk_w, planes.device)
+    _check(L.sq_blosc_encode_planes(planes.data_ptr(), planes.stride(0) if n > 1 else h * planes.stride(1), planes.stride(1), n, h, w,
+                                    sq_dtype_of(npdt), int(chunk_h), int(chunk_w), buffers.scratch.data_ptr(),
+                                    buffers.scratch.numel(), buffers.offsets.data_ptr(), buffers.out.data_ptr(), buffers.out.numel(),
+                                    buffers.status.data_ptr(), _stream_ptr(stream)), 'sq_blosc_encode_planes')
+    return buffers
 
 
 def basic_fit(tiles, smoothness_flatfield: float = 1.0, stream=None):

@@ -54,7 +54,7 @@ class Signal:
 
 class Stitcher:
     def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
-                 normalization: Optional[str] = 'phase', zarr_compression: str = 'zlib',
+                 normalization: Optional[str] = 'phase', zarr_compression: str = 'blosc',
                  per_region_registration: bool = False, flatfield_estimator: str = 'auto'):
         self.update_progress = Signal(int, int)
         self.getting_flatfields = Signal()
@@ -82,8 +82,8 @@ class Stitcher:
             raise ValueError("fusion_mode must be 'overwrite' or 'feather'")
         self.fusion_mode = fusion_mode            # 'feather' is an extension the reference lacks
         self.normalization = normalization        # scikit-image >= 0.19 default is 'phase'
-        if zarr_compression not in ('zlib', 'none'):
-            raise ValueError("zarr_compression must be 'zlib' or 'none'")
+        if zarr_compression not in ('blosc', 'zlib', 'none'):
+            raise ValueError("zarr_compression must be 'blosc', 'zlib' or 'none'")
         self.zarr_compression = zarr_compression
         if flatfield_estimator not in ('auto', 'basic', 'basicpy', 'mean'):
             raise ValueError("flatfield_estimator must be 'auto', 'basic', 'basicpy' or 'mean'")

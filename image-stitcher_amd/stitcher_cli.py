@@ -30,8 +30,9 @@ FLAGS = (
                               help="overwrite = the reference's last-writer-wins; feather = distance-weighted blend (extension)")),
     (('--normalization',), dict(choices=['phase', 'none'], default='phase',
                                 help="cross-power normalisation: phase = scikit-image >= 0.19 default, none = 0.18 behaviour")),
-    (('--zarr-compression',), dict(choices=['zlib', 'none'], default='zlib',
-                                   help="OME-Zarr chunk compressor (none = raw chunks)")),
+    (('--zarr-compression',), dict(choices=['blosc', 'zlib', 'none'], default='blosc',
+                                   help="OME-Zarr chunk codec: blosc = the reference's default (Blosc-1 frames, shuffle + LZ4), encoded "
+                                        "on the device; zlib = host threads; none = raw chunks")),
     (('--per-region-registration',), dict(action='store_true',
                                           help="with -r: register every (timepoint, region) on its own tiles instead of once")),
     (('--flatfield-estimator',), dict(choices=['auto', 'basic', 'basicpy', 'mean'], default='auto',

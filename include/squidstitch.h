@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 102 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit */
+#define SQ_VERSION 102 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit, sq_blosc_* */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -216,6 +216,22 @@ typedef struct sq_register_args {
  * Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Chunk encoding on the device: the chunks of n_planes (t, c, z) planes (chunk_h x chunk_w elements,
+ * zero-padded past the plane's edge like zarr pads edge chunks) as Blosc-1 frames -- byte shuffle + LZ4, the
+ * default codec of the store the reference writes (zarr.storage.default_compressor, stitcher.py:814-818) -- packed
+ * densely into out_dev: chunk i = plane-major, then chunk row, then chunk column, lives at
+ * out_dev[offsets_dev[i] .. offsets_dev[i + 1]) (n_chunks + 1 offsets; an all-zero chunk has size 0: the store's
+ * fill_value stands for it).  *status_dev != 0 afterwards: out_capacity was too small (sq_blosc_out_bound() never is).
+ * Strides in elements; dtype SQ_U8 or SQ_U16.  Asynchronous on `stream` like the other entry points.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sq_blosc_chunk_count(int32_t n_planes, int32_t h, int32_t w, int32_t chunk_h, int32_t chunk_w);
+int64_t sq_blosc_out_bound(int32_t n_planes, int32_t h, int32_t w, int32_t dtype, int32_t chunk_h, int32_t chunk_w);
+int64_t sq_blosc_scratch_bytes(int32_t n_planes, int32_t h, int32_t w, int32_t dtype, int32_t chunk_h, int32_t chunk_w);
+int sq_blosc_encode_planes(const void *planes_dev, int64_t plane_stride, int64_t pitch, int32_t n_planes, int32_t h, int32_t w,
+                           int32_t dtype, int32_t chunk_h, int32_t chunk_w, void *scratch_dev, int64_t scratch_bytes,
+                           uint64_t *offsets_dev, void *out_dev, int64_t out_capacity, uint32_t *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flatfield ESTIMATE: replaces basicpy.BaSiC(get_darkfield=False, smoothness_flatfield=s).fit(images).flatfield

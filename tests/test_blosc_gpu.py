@@ -1,0 +1,127 @@
+"""Device chunk encoder (csrc/blosc.hip): every frame decodes, with an INDEPENDENT reader (tests/blosc_ref.py), to the
+zero-padded chunk zarr would store; stores written with the device codec are read back through a spec-level reader that
+shares nothing with omezarr.py; their metadata is what zarr's default compressor / the reference's writer produce."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import blosc_ref
+from image_stitcher_amd import native, omezarr, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def encode(planes_np, cy, cx, strided=False):
+    import torch
+    t = torch.from_numpy(planes_np).to(_dev())
+    if strided:      # padded plane stride and row pitch
+        n, h, w = planes_np.shape
+        big = torch.zeros((n, h + 3, w + 5), dtype=t.dtype, device=t.device)
+        big[:, :h, :w] = t
+        t = big[:, :h, :w]
+    buf = native.blosc_encode_planes(t, cy, cx)
+    torch.cuda.synchronize()
+    assert int(buf.status.item()) == 0
+    return buf.offsets.cpu().numpy(), buf.out.cpu().numpy()
+
+
+def expected_chunk(plane, iy, ix, cy, cx):
+    full = np.zeros((cy, cx), dtype=plane.dtype)
+    part = plane[iy * cy:(iy + 1) * cy, ix * cx:(ix + 1) * cx]
+    full[:part.shape[0], :part.shape[1]] = part
+    return full
+
+
+CASES = [   # (planes, h, w, dtype, cy, cx, kind)
+    (2, 100, 130, 'uint16', 64, 64, 'scene'), (1, 512, 512, 'uint16', 512, 512, 'scene'), (3, 70, 33, 'uint8', 32, 32, 'scene'),
+    (1, 300, 1000, 'uint16', 128, 512, 'random'), (2, 257, 129, 'uint16', 128, 128, 'ramp'), (1, 64, 64, 'uint16', 512, 512, 'scene'),
+    (1, 640, 520, 'uint16', 512, 512, 'blocks'), (1, 200, 200, 'uint8', 200, 200, 'constant'), (2, 5, 7, 'uint16', 4, 4, 'random'),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[f'{c[1]}x{c[2]}-{c[3]}-{c[4]}x{c[5]}-{c[6]}' for c in CASES])
+def test_every_frame_decodes_to_the_padded_chunk(case):
+    n, h, w, dtype, cy, cx, kind = case
+    rng = np.random.default_rng(h * w)
+    info = np.iinfo(dtype)
+    if kind == 'scene':
+        planes = np.stack([synth.scene_patch(7 + p, 50, 60, h, w) for p in range(n)])
+        planes = (planes >> (8 if dtype == 'uint8' else 0)).astype(dtype)
+    elif kind == 'random':
+        planes = rng.integers(0, info.max + 1, (n, h, w)).astype(dtype)
+    elif kind == 'ramp':       # long exact matches (length extension bytes), overlapping copies
+        planes = np.broadcast_to((np.arange(w) // 9 % 200).astype(dtype), (n, h, w)).copy()
+    elif kind == 'blocks':     # half the canvas zero (all-zero chunks are dropped), the rest 8 x 8 constant blocks
+        planes = np.zeros((n, h, w), dtype)
+        planes[:, :h // 2] = np.kron(rng.integers(1, info.max, (n, h // 16, (w + 7) // 8)), np.ones((8, 8), int))[:, :h // 2, :w].astype(dtype)
+    else:
+        planes = np.full((n, h, w), 777 % info.max, dtype)
+    for strided in (False, True):
+        offsets, out = encode(planes, cy, cx, strided)
+        ncy, ncx = -(-h // cy), -(-w // cx)
+        assert len(offsets) == n * ncy * ncx + 1 and offsets[0] == 0 and np.all(np.diff(offsets) >= 0)
+        raw_total = 0
+        for p in range(n):
+            for iy in range(ncy):
+                for ix in range(ncx):
+                    i = (p * ncy + iy) * ncx + ix
+                    frame = out[offsets[i]:offsets[i + 1]].tobytes()
+                    want = expected_chunk(planes[p], iy, ix, cy, cx)
+                    if not want.any():
+                        assert len(frame) == 0          # fill_value stands for it
+                        continue
+                    hd = blosc_ref.parse_header(frame)
+                    assert (hd['version'], hd['versionlz'], hd['codec'], hd['typesize']) == (2, 1, 1, planes.dtype.itemsize)
+                    assert hd['nbytes'] == want.nbytes and hd['cbytes'] == len(frame) and hd['blocksize'] == min(16384, want.nbytes)
+                    assert hd['dont_split'] and hd['shuffle'] == (planes.dtype.itemsize > 1) and not hd['memcpyed']
+                    assert blosc_ref.blosc_decompress(frame) == want.tobytes()
+                    assert omezarr.blosc_decode(frame) == want.tobytes()
+                    assert len(frame) <= want.nbytes + 16 + 8 * (-(-want.nbytes // 16384))
+                    raw_total += want.nbytes
+        if kind in ('ramp', 'constant', 'blocks') and raw_total:
+            assert offsets[-1] < raw_total / 8            # these compress well
+        if kind == 'scene' and dtype == 'uint16' and raw_total:
+            assert offsets[-1] < raw_total                 # the high bytes of a smooth scene do
+
+
+@pytest.mark.parametrize('compression', ['blosc'])
+def test_store_with_device_codec_through_the_spec_level_reader(tmp_path, compression):
+    """Three pyramid levels, chunks (1,1,1,128,256), 2 channels x 3 z, partial last batch: the store read with
+    tests/blosc_ref.py (zarr v2 + NGFF 0.4 from the specs) equals the planes and their nearest-neighbour pyramid;
+    .zarray carries zarr's default compressor configuration; keys use the '/' separator."""
+    import torch
+    from oracle import stitch_oracle as O
+    rng = np.random.default_rng(5)
+    img = np.stack([synth.scene_patch(30 + k, 0, 0, 700, 900) for k in range(6)]).astype(np.uint16).reshape(1, 2, 3, 700, 900)
+    img[0, 1, 2, :, :] = 0                                             # one all-zero plane
+    path = str(tmp_path / 'img.ome.zarr')
+    shapes = omezarr.create_store(path, img.shape, img.dtype, pixel_size_um=0.5, dz_um=1.5, channel_names=['a', 'b'],
+                                  channel_colors=[0xFF0000, 0x00FF00], num_levels=3, chunks=(1, 1, 1, 128, 256), compression=compression)
+    coords = [(0, c, z) for c in range(2) for z in range(3)]
+    planes = torch.from_numpy(img.reshape(6, 700, 900)).to(_dev())
+    with omezarr.PlaneStreamWriter(path, shapes, img.dtype, chunks=(1, 1, 1, 128, 256), batch=4, compression=compression,
+                                   device=_dev()) as writer:
+        for b0 in (0, 4):
+            part = planes[b0:b0 + 4]
+            writer.acquire(len(part)).copy_(part)
+            writer.submit(coords[b0:b0 + 4])
+    blosc_ref.check_ngff_group(path, 3, img.shape, 0.5, 1.5, ['a', 'b'])
+    want_levels = O.pyramid_nearest(img, 3)
+    for lv in range(3):
+        got, meta, seen = blosc_ref.read_zarr_v2_array(os.path.join(path, str(lv)))
+        np.testing.assert_array_equal(got, want_levels[lv])
+        assert meta['compressor'] == {'id': 'blosc', 'cname': 'lz4', 'clevel': 5, 'shuffle': 1, 'blocksize': 0}
+        assert meta['dtype'] == '<u2' and meta['fill_value'] == 0 and meta['dimension_separator'] == '/'
+        assert meta['chunks'] == [1, 1, 1, min(128, got.shape[3]), min(256, got.shape[4])]
+        np.testing.assert_array_equal(omezarr.read_array(os.path.join(path, str(lv))), want_levels[lv])
+        assert not os.path.exists(os.path.join(path, str(lv), '0', '1', '2'))     # the all-zero plane wrote nothing
+        assert seen > 0
+    assert writer.bytes_written < img.nbytes
