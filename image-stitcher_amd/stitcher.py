@@ -901,24 +901,6 @@ class Stitcher:
                       fh, indent=1)
 
     # --------------------------------------------------------------------- run
-    # The reference's Stitcher is a QThread: GUIs call start() and listen to the signals.  The same
-    # three calls work here on a plain thread.
-    def start(self):
-        import threading
-        self._thread = threading.Thread(target=self.run, name='Stitcher', daemon=True)
-        self._thread.start()
-
-    def isRunning(self) -> bool:
-        t = getattr(self, '_thread', None)
-        return bool(t and t.is_alive())
-
-    def wait(self, timeout_ms: Optional[int] = None) -> bool:
-        t = getattr(self, '_thread', None)
-        if t is None:
-            return True
-        t.join(None if timeout_ms is None else timeout_ms / 1000.0)
-        return not t.is_alive()
-
     def run(self):
         """(stitcher.py:1226-1299): metadata, [flatfields], [shifts once], then every
         timepoint x region: stitch + save."""

@@ -124,8 +124,9 @@ def test_feather_mode_runs_and_agrees_with_overwrite_away_from_seams(tmp_path):
     np.testing.assert_array_equal(canvas[0, 0, 0, 50:80, 50:80], ref[0, 0, 0, 50:80, 50:80])
 
 
-def test_thread_style_start_wait_and_signals(tmp_path):
-    """GUI-style use: start() in the background, signals fire, wait() joins (the reference is a QThread)."""
+def test_run_fires_the_reference_signals(tmp_path):
+    """run() (what stitcher_cli calls, and what a QThread front-end would start) fires the reference's signals
+    (stitcher.py:33-37) in its order."""
     info, arrays = load_case('reg_neg_skew')
     root = str(tmp_path / 'acq')
     synth.write_acquisition(spec_of(info), root)
@@ -135,8 +136,7 @@ def test_thread_style_start_wait_and_signals(tmp_path):
     st.starting_stitching.connect(lambda: seen.__setitem__('started', seen['started'] + 1))
     st.starting_saving.connect(lambda final: seen['saving'].append(final))
     st.finished_saving.connect(lambda path, dtype: seen.__setitem__('finished', (path, dtype)))
-    st.start()
-    assert st.wait(120000) and not st.isRunning()
+    st.run()
     assert seen['started'] == 1 and seen['progress'] == 9 and seen['saving'] == [False, True]
     path, dtype = seen['finished']
     assert path.endswith(os.path.join('0_stitched', 'R0_stitched.ome.zarr')) and dtype == np.uint16

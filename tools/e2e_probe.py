@@ -44,8 +44,8 @@ def stream_vs_sequential(spec, batch_bytes):
         import torch
         t0 = time.time(); synth.write_acquisition_device(spec, root, torch.device('cuda:0')); t_write = time.time() - t0
         print(f'stream probe: {spec.rows}x{spec.cols} x {spec.tile_h}^2, {len(spec.channels)} ch x {spec.nz} z; tiles written in {t_write:.1f}s', flush=True)
-        for compression in ('zlib', 'none'):
-            for mode in ('sequential', 'streamed'):
+        for compression in ('blosc', 'zlib', 'none'):
+            for mode in (('streamed',) if compression == 'blosc' else ('sequential', 'streamed')):
                 st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), zarr_compression=compression)
                 st.output_folder = os.path.join(tmp, f'out_{compression}_{mode}')
                 st.batch_bytes_limit = batch_bytes
