@@ -245,3 +245,39 @@ def test_config4_full_size_plane_and_25_planes_through_the_work_queues():
     assert torch.equal(single[0].view(torch.int16), ref[0])
     del canvas, single, tiles
     torch.cuda.empty_cache()
+
+
+def test_config5_full_plate_96_wells_per_well_registration(tmp_path):
+    """BASELINE config 5 in its full SHAPE: a 96-well plate (A1..H12), 5x5 tiles per well, 3 channels, per-well
+    registration, streamed to OME-Zarr -- with small tiles (96 x 128) and T = 2 so that the 14 400 files are written
+    in seconds (the voxel count scales with the tile size, the bookkeeping does not: 192 (timepoint, well) units,
+    192 registrations, 192 stores, one 192-row shift table).  A sample of wells is compared with the oracle voxel for
+    voxel (store read through the independent spec-level reader); every unit has its row in shift_table.json."""
+    import json
+    import blosc_ref
+    wells = tuple(f'{r}{c}' for r in 'ABCDEFGH' for c in range(1, 13))
+    spec = synth.GridSpec(rows=5, cols=5, tile_h=96, tile_w=128, ov_y=24, ov_x=32, seed=5100, regions=wells, nt=2,
+                          channels=synth.DEFAULT_CHANNELS[:3])
+    root = str(tmp_path / 'plate')
+    synth.write_acquisition(spec, root)
+    from image_stitcher_amd import stitcher_cli
+    stitcher_cli.main(['-i', root, '-r', '--per-region-registration'])
+    (out,) = [d for d in os.listdir(tmp_path) if d.startswith('plate_stitched_')]
+    with open(os.path.join(tmp_path, out, 'shift_table.json')) as fh:
+        table = json.load(fh)
+    assert table['per_region_registration'] is True and len(table['shifts']) == 192
+    assert [(e['timepoint'], e['region']) for e in table['shifts']] == [(t, w) for t in (0, 1) for w in sorted(wells)]
+    acq = O.parse_acquisition(root, read_image)
+    rows = {(e['timepoint'], e['region']): e for e in table['shifts']}
+    for t, well in ((0, 'A1'), (0, 'D7'), (1, 'H12'), (1, 'B10')):
+        want_s = O.calculate_shifts(acq, t, well, read_image, '', 0, 'Unidirectional', 'phase')
+        e = rows[(t, well)]
+        assert (tuple(e['h_shift']), tuple(e['v_shift'])) == (tuple(want_s['h_shift']), tuple(want_s['v_shift']))
+        want = O.stitch_region(acq, t, well, read_image, True, want_s)
+        store = os.path.join(tmp_path, out, f'{t}_stitched', f'{well}_stitched.ome.zarr')
+        got, meta, _ = blosc_ref.read_zarr_v2_array(os.path.join(store, '0'))
+        np.testing.assert_array_equal(got, want)
+        assert meta['compressor']['id'] == 'blosc'
+    stores = sum(1 for t in (0, 1) for w in wells
+                 if os.path.isfile(os.path.join(tmp_path, out, f'{t}_stitched', f'{w}_stitched.ome.zarr', '.zattrs')))
+    assert stores == 192
