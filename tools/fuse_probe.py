@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
     ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
     ap.add_argument('--flags', type=int, default=0)
+    ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g, T = a.grid, a.tile
@@ -56,13 +57,13 @@ def main():
             ffs = [torch.from_numpy(g).to(dev) for _ in range(a.nflats)]
         flats = [ffs[p * a.nflats // a.planes] for p in range(a.planes)]
     for _ in range(2):
-        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags)
+        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags, grid_blocks=a.blocks)
     torch.cuda.synchronize()
     evs = []
     for _ in range(a.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags)
+        native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags, grid_blocks=a.blocks)
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
