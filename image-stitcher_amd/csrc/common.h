@@ -36,6 +36,12 @@ constexpr uint32_t TABLE_MAGIC = 0x53514654u;  // "SQFT"
 constexpr int BLOCK_ROWS = SQ_BLOCK_ROWS;      // rows of a span one workgroup takes (multiple of 4: one wave per row)
 constexpr int BLOCK_COLS = SQ_BLOCK_COLS;      // columns of a span one workgroup takes
 constexpr int MAX_REFS = 8;                    // feather: most tiles blended in one span
+#ifndef SQ_FEATHER_BLEND_ROWS
+#define SQ_FEATHER_BLEND_ROWS 32
+#endif
+constexpr int FEATHER_BLEND_ROWS = SQ_FEATHER_BLEND_ROWS;   // feather: rows of an item of a span several tiles cover: every
+                                               // thread of the workgroup then walks several (row, group) pairs of the item
+                                               // and loads the next pair's pixels before it blends the current one
 
 struct TableHeader {
     uint32_t magic;

@@ -672,19 +672,36 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
 struct UnitAux {
     PlaneGroup g;
     const void *tile[ZB];
+    int32_t a, b, c, pad;   // feather: tile index and source origin of a one-tile item (looked up through its Ref)
 };
 
+// RND = 0 (overwrite: truncate): Markstein with r = v_rcp_f32(g), the arithmetic of div_u16_normal.
+// RND = 1 (feather, a voxel one tile covers: round half to even): the arithmetic of div_u16_normal_ieee with its Newton
+// step on the reciprocal hoisted -- r arrives refined (recip_for), two exact-residual corrections here, v_rndne.
+template <int RND>
+__device__ __forceinline__ float recip_for(float g) {
+    float r = __builtin_amdgcn_rcpf(g);
+    if (RND) r = fmaf(fmaf(-g, r, 1.0f), r, r);
+    return r;
+}
+template <int RND>
+__device__ __forceinline__ float quot_one(float n, float g, float r) {
+    float q = n * r;
+    q = fmaf(fmaf(-g, q, n), r, q);
+    if (RND) q = __builtin_rintf(fmaf(fmaf(-g, q, n), r, q));
+    return q;
+}
+template <int RND>
 __device__ __forceinline__ uint32_t quot_pair(uint32_t word, float g_lo, float g_hi, float r_lo, float r_hi) {
     const float n0 = (float)(word & 0xFFFFu), n1 = (float)(word >> 16);
-    const float q0 = n0 * r_lo, q1 = n1 * r_hi;
-    const uint32_t a = cvt_u32_sat(fmaf(fmaf(-g_lo, q0, n0), r_lo, q0));
-    const uint32_t b = cvt_u32_sat(fmaf(fmaf(-g_hi, q1, n1), r_hi, q1));
+    const uint32_t a = cvt_u32_sat(quot_one<RND>(n0, g_lo, r_lo));
+    const uint32_t b = cvt_u32_sat(quot_one<RND>(n1, g_hi, r_hi));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
 
-template <bool FULL>
+template <bool FULL, int RND = 0>
 __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
                                                 const int wave, const int lane) {
     typedef uint16_t T;
@@ -744,27 +761,25 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             f32x4 r0, r1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                r0[c] = __builtin_amdgcn_rcpf(g0[c]);
-                r1[c] = __builtin_amdgcn_rcpf(g1[c]);
+                r0[c] = recip_for<RND>(g0[c]);
+                r1[c] = recip_for<RND>(g1[c]);
             }
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
                     u32x4 o;
-                    o[0] = quot_pair(px[z][0], g0[0], g0[1], r0[0], r0[1]);
-                    o[1] = quot_pair(px[z][1], g0[2], g0[3], r0[2], r0[3]);
-                    o[2] = quot_pair(px[z][2], g1[0], g1[1], r1[0], r1[1]);
-                    o[3] = quot_pair(px[z][3], g1[2], g1[3], r1[2], r1[3]);
+                    o[0] = quot_pair<RND>(px[z][0], g0[0], g0[1], r0[0], r0[1]);
+                    o[1] = quot_pair<RND>(px[z][1], g0[2], g0[3], r0[2], r0[3]);
+                    o[2] = quot_pair<RND>(px[z][2], g1[0], g1[1], r1[0], r1[1]);
+                    o[3] = quot_pair<RND>(px[z][3], g1[2], g1[3], r1[2], r1[3]);
                     if (act) stg_nt(cplane[z] + doff + p0, o);
                 }
         }
-        const float er = __builtin_amdgcn_rcpf(eg);
+        const float er = recip_for<RND>(eg);
 #pragma unroll
         for (int z = 0; z < ZB; ++z)
             if (FULL || z < gn) {
-                const float nf = (float)e[z];
-                const float q = nf * er;
-                const uint32_t kq = min(cvt_u32_sat(fmaf(fmaf(-eg, q, nf), er, q)), 65535u);
+                const uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
                 if (ep >= 0) stg_s<T>(cplane[z] + doff + ep, (T)kq);
             }
     }
@@ -784,6 +799,10 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
         A.g = P.groups[unit];
 #pragma unroll
         for (int z = 0; z < ZB; ++z) A.tile[z] = (it.nref && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], it.a) : nullptr;
+        A.a = it.a;
+        A.b = it.b;
+        A.c = it.c;
+        A.pad = 0;
         return A;
     };
     auto body = [&](int, const Item &it, const UnitAux &A) {
@@ -898,11 +917,13 @@ __device__ __forceinline__ OutT feather_out(float o) {
 // One 8-pixel group (p0 .. p0+7 of item row r) blended from the item's references.  The loads of up
 // to four references (pixels and gains) are issued before the first use; references are
 // wave-uniform, so the loops over them run on scalar registers.
+constexpr int BLEND_MAXR = 4;   // references whose pixel vectors are loaded ahead (more than 4 tiles meet nowhere in a grid)
+
 template <typename T, typename OutT, int FLAT, bool FAST>
 __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, const Item &it, const char *flat, int r, int p0,
-                                            OutT *dst) {
+                                            OutT *dst, const u32x4 *pre = nullptr) {
     constexpr int VEC = 8;
-    constexpr int MAXR = 4;
+    constexpr int MAXR = BLEND_MAXR;
     const int nref = it.nref;
     float acc[VEC], wsum[VEC], last[VEC];
 #pragma unroll
@@ -928,7 +949,7 @@ __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, cons
                 const Ref rf = P.refs[it.a + k];
                 ys[k] = rf.src_y + it.b + r;
                 xs[k] = rf.src_x + it.c + p0;
-                raw[k] = ldg<U32x4U>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)ys[k] * P.tile_pitch + xs[k]);
+                raw[k] = pre ? pre[k] : ldg<U32x4U>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)ys[k] * P.tile_pitch + xs[k]);
                 if (FLAT == 1 && flat) {
                     const float *gp = reinterpret_cast<const float *>(flat) + (int64_t)ys[k] * P.tile_w + xs[k];
                     g[k][0] = ldg<F32x4U>(gp);
@@ -1007,14 +1028,64 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
     OutT *canvas = static_cast<OutT *>(P.canvas) + plane * P.canvas_plane_stride;
     const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
     const int G = n / VEC + 1;   // upper bound of the whole groups of a row
-    for (int idx = tid; idx < rows * G; idx += 256) {
-        const int r = idx / G, j = idx - r * G;
+    auto locate = [&](int idx, int &r, int &p0, OutT *&dst) -> bool {   // (row, group) pair idx -> where it lives; false: no such group
+        r = idx / G;
+        const int j = idx - r * G;
         OutT *drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
         const int mis = (int)((reinterpret_cast<uintptr_t>(drow) / sizeof(OutT)) & (VEC - 1));
         const int v = (mis ? 1 : 0) + j;
-        if (v >= (n + mis) / VEC) continue;
-        const int p0 = v * VEC - mis;
-        blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, drow + p0);
+        p0 = v * VEC - mis;
+        dst = drow + p0;
+        return v < (n + mis) / VEC;
+    };
+    if (sizeof(T) == 2 && FLAT != 2 && nref <= BLEND_MAXR) {
+        // software pipeline over this thread's pairs: the pixel vectors of the NEXT pair (one per covering tile) are in
+        // flight while the current pair is blended -- a 244-pixel strip is otherwise one dependent load -> blend -> store
+        // chain per thread and item (measured: latency, not arithmetic, bounded the blend)
+        const T *tiles[BLEND_MAXR];
+        int sy[BLEND_MAXR], sx[BLEND_MAXR];
+#pragma unroll
+        for (int k = 0; k < BLEND_MAXR; ++k) {
+            const Ref rf = P.refs[it.a + (k < nref ? k : 0)];
+            tiles[k] = tile_ptr<T>(P, plane, rf.tile);
+            sy[k] = rf.src_y + it.b;
+            sx[k] = rf.src_x + it.c;
+        }
+        auto load = [&](int r, int p0, u32x4 (&raw)[BLEND_MAXR]) {
+#pragma unroll
+            for (int k = 0; k < BLEND_MAXR; ++k)
+                if (k < nref) raw[k] = ldg<U32x4U>(tiles[k] + (int64_t)(sy[k] + r) * P.tile_pitch + sx[k] + p0);
+        };
+        const int total = rows * G;
+        int r = 0, p0 = 0;
+        OutT *dst = nullptr;
+        u32x4 raw[BLEND_MAXR];
+        int idx = tid;
+        bool have = idx < total && locate(idx, r, p0, dst);
+        if (have) load(r, p0, raw);
+        while (idx < total) {
+            const int nidx = idx + 256;
+            int nr = 0, np0 = 0;
+            OutT *ndst = nullptr;
+            u32x4 nraw[BLEND_MAXR];
+            const bool nhave = nidx < total && locate(nidx, nr, np0, ndst);
+            if (nhave) load(nr, np0, nraw);
+            if (have) blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, dst, raw);
+            idx = nidx;
+            have = nhave;
+            r = nr;
+            p0 = np0;
+            dst = ndst;
+#pragma unroll
+            for (int k = 0; k < BLEND_MAXR; ++k) raw[k] = nraw[k];
+        }
+    } else {
+        for (int idx = tid; idx < rows * G; idx += 256) {
+            int r, p0;
+            OutT *dst;
+            if (!locate(idx, r, p0, dst)) continue;
+            blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, dst);
+        }
     }
     for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
         const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
@@ -1090,6 +1161,67 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
         for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
             const int plane = (int)(work / n_items);
             one_item(plane, P.items[work - plane * n_items]);
+        }
+    }
+}
+
+// Feather mode, uint16 tiles and canvas, float32 gains: the plane groups of the overwrite kernel.  One-tile items (77 %
+// of the covered area at 244-pixel overlaps) go through process_item_zg<.., RND = 1> -- gains and their refined
+// reciprocals once per group, every bit of the result that of div_u16_normal_ieee + rint -- blended items plane by plane.
+template <bool DYN>
+__global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_feather_zg_kernel(const FuseParams P, const int64_t n_items) {
+    typedef uint16_t T;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_groups = *P.n_groups;
+    auto pre = [&](int unit, const Item &it) -> UnitAux {
+        UnitAux A;
+        A.g = P.groups[unit];
+        A.a = A.b = A.c = A.pad = 0;
+        Ref rf{};
+        if (it.nref == 1) {
+            rf = P.refs[it.a];
+            A.a = rf.tile;
+            A.b = rf.src_y + it.b;
+            A.c = rf.src_x + it.c;
+        }
+#pragma unroll
+        for (int z = 0; z < ZB; ++z) A.tile[z] = (it.nref == 1 && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], rf.tile) : nullptr;
+        return A;
+    };
+    auto body = [&](int, const Item &it, const UnitAux &A) {
+        const int gn = sgpr(A.g.n);
+        if (it.nref <= 1) {
+            Item one = it;
+            one.a = sgpr(A.a);
+            one.b = sgpr(A.b);
+            one.c = sgpr(A.c);
+            if (gn == 1) process_item<T, 1, 1>(P, sgpr(A.g.plane[0]), one, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
+            else if (gn == ZB) process_item_zg<true, 1>(P, A, gn, one, wave, lane);
+            else process_item_zg<false, 1>(P, A, gn, one, wave, lane);
+            return;
+        }
+        for (int z = 0; z < gn; ++z) {
+            const int plane = sgpr(A.g.plane[z]);
+            if (P.flat_class[plane] == 0) blend_item<T, T, 1, true>(P, plane, it, threadIdx.x);
+            else blend_item<T, T, 1, false>(P, plane, it, threadIdx.x);
+        }
+    };
+    if (DYN) {
+        for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);
+    } else {
+        __shared__ Item s_it;
+        __shared__ UnitAux s_A;
+        const int64_t n_work = (int64_t)n_groups * n_items;
+        for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int unit = (int)(work / n_items);
+                s_it = P.items[work - unit * n_items];
+                s_A = pre(unit, s_it);
+            }
+            __syncthreads();
+            body(0, sgpr(s_it), s_A);
         }
     }
 }
@@ -1397,6 +1529,17 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     const bool f32out = a->canvas_dtype == SQ_F32;
     if (!f32out && a->canvas_dtype != a->tile_dtype)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: feather canvas must be float32 or the tile dtype");
+    if (u16 && !f32out && flat == 1 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
+        char *sc = static_cast<char *>(a->scratch_dev);
+        uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
+        PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
+        hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, a->n_planes,
+                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
+        P.groups = groups;
+        P.n_groups = n_groups;
+        if (P.queue) return launch_zg(fuse_feather_zg_kernel<true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        return launch_zg(fuse_feather_zg_kernel<false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+    }
 #define SQ_FEATHER_F(T, O, F)                                                                              \
     do {                                                                                                    \
         if (P.queue) return launch(fuse_feather_kernel<T, O, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);  \

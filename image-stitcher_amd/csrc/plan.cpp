@@ -310,12 +310,15 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             const size_t si = span_order[so];
             const Span &sp = spans[si];
             const Ref *rf = (mode == SQ_FUSE_OVERWRITE && sp.nref) ? &refs[sp.ref0] : nullptr;
-            for (int r0 = 0; r0 < sp.h; r0 += BLOCK_ROWS)
+            // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
+            // workgroup (fuse.hip blend_item): taller items there, so that a thread has a next pair to load ahead
+            const int item_rows = (mode == SQ_FUSE_FEATHER && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
+            for (int r0 = 0; r0 < sp.h; r0 += item_rows)
                 for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
                     Item it;
                     it.dst_y = sp.dst_y + r0;
                     it.dst_x = sp.dst_x + c0;
-                    it.hw = (std::min(BLOCK_ROWS, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
+                    it.hw = (std::min(item_rows, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
                     it.nref = sp.nref;
                     it.span = (int32_t)si;
                     if (mode == SQ_FUSE_OVERWRITE) {
