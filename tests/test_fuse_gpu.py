@@ -399,3 +399,59 @@ def test_work_queues_on_a_registered_grid(planes):
     assert plan.n_items > 64
     for p in range(planes):
         np.testing.assert_array_equal(got[p], O.fuse_plane_overwrite(list(tiles[p]), rects, hc, wc, flats[p]))
+
+
+@pytest.mark.parametrize('mode', [native.SQ_FUSE_OVERWRITE, native.SQ_FUSE_FEATHER])
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('queues', [False, True])
+def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
+    """Planes that share a gain image go through an item together (gains and reciprocals once per group) when the canvas
+    planes start on 128-byte lines (native.empty_canvas).  Random registered-grid-like geometry, 1..12 planes dealt to 1..3
+    gain images (one of them with a zero: that plane takes the generic divide in a group of its own), full groups of 5,
+    partial groups, a plane without gains; both fusion modes, static walk and device queues: every plane equals the
+    oracle.  The same planes on a DENSE stack (groups of one) give the same voxels."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(4200 + seed)
+    th, tw = int(rng.integers(20, 70)), int(rng.integers(40, 260))
+    rows, cols = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    oy, ox = int(rng.integers(2, th // 3)), int(rng.integers(2, tw // 3))
+    n = rows * cols
+    crop = mode == native.SQ_FUSE_OVERWRITE
+    rects = np.zeros((n, 6), dtype=np.int64)
+    for r in range(rows):
+        for c in range(cols):
+            top, left = (oy // 2 if r and crop else 0), (ox // 2 if c and crop else 0)
+            bottom, right = (oy // 2 if r < rows - 1 and crop else 0), (ox // 2 if c < cols - 1 and crop else 0)
+            rects[r * cols + c] = (top, left, th - top - bottom, tw - left - right,
+                                   r * (th - oy) + top + c * 2, c * (tw - ox) + left + (rows - 1 - r) * 3)
+    ch = int(rects[:, 4].max() + th + rng.integers(0, 9))
+    cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
+    planes = int(rng.integers(1, 13))
+    tiles = rng.integers(0, 65536, size=(planes, n, th, tw)).astype(np.uint16)
+    gains = [np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float32) for _ in range(3)]
+    gains[2][rng.integers(0, th), rng.integers(0, tw)] = 0.0            # this image needs the generic divide
+    which = [int(rng.integers(0, 3)) if rng.random() > 0.1 else -1 for _ in range(planes)]
+    if planes >= 7:
+        which[:6] = [0] * 6                                              # a full group of 5 and a leftover
+    d_gains = [torch.from_numpy(g).to(dev) for g in gains]
+    flats = [None if k < 0 else d_gains[k] for k in which]
+    plan = native.FusePlan(rects, th, tw, ch, cw, mode)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    aligned = native.empty_canvas(planes, ch, cw, torch.uint16, dev)
+    aligned.view(torch.int16).fill_(-1)
+    dense = torch.full((planes, ch, cw), 7, dtype=torch.uint16, device=dev)
+    if any(f is not None for f in flats):
+        native.fuse_planes(plan, d_tiles, aligned, flats, flags=flags)
+        native.fuse_planes(plan, d_tiles, dense, flats, flags=flags | native.SQ_FUSE_NO_PLANE_GROUPS)
+    else:
+        native.fuse_planes(plan, d_tiles, aligned, None, flags=flags)
+        native.fuse_planes(plan, d_tiles, dense, None, flags=flags)
+    torch.cuda.synchronize()
+    for p in range(planes):
+        g = None if which[p] < 0 else gains[which[p]]
+        want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, g) if mode == native.SQ_FUSE_OVERWRITE else \
+            O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, g, out_dtype=np.uint16)
+        np.testing.assert_array_equal(aligned[p].cpu().numpy(), want, err_msg=f'plane {p} (gain image {which[p]}) of {planes}')
+        np.testing.assert_array_equal(dense[p].cpu().numpy(), want, err_msg=f'dense plane {p}')
