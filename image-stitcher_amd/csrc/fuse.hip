@@ -921,7 +921,7 @@ constexpr int BLEND_MAXR = 4;   // references whose pixel vectors are loaded ahe
 
 template <typename T, typename OutT, int FLAT, bool FAST>
 __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, const Item &it, const char *flat, int r, int p0,
-                                            OutT *dst, const u32x4 *pre = nullptr) {
+                                            OutT *dst) {
     constexpr int VEC = 8;
     constexpr int MAXR = BLEND_MAXR;
     const int nref = it.nref;
@@ -949,7 +949,7 @@ __device__ __forceinline__ void blend_group(const FuseParams &P, int plane, cons
                 const Ref rf = P.refs[it.a + k];
                 ys[k] = rf.src_y + it.b + r;
                 xs[k] = rf.src_x + it.c + p0;
-                raw[k] = pre ? pre[k] : ldg<U32x4U>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)ys[k] * P.tile_pitch + xs[k]);
+                raw[k] = ldg<U32x4U>(tile_ptr<T>(P, plane, rf.tile) + (int64_t)ys[k] * P.tile_pitch + xs[k]);
                 if (FLAT == 1 && flat) {
                     const float *gp = reinterpret_cast<const float *>(flat) + (int64_t)ys[k] * P.tile_w + xs[k];
                     g[k][0] = ldg<F32x4U>(gp);
@@ -1038,54 +1038,14 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
         dst = drow + p0;
         return v < (n + mis) / VEC;
     };
-    if (sizeof(T) == 2 && FLAT != 2 && nref <= BLEND_MAXR) {
-        // software pipeline over this thread's pairs: the pixel vectors of the NEXT pair (one per covering tile) are in
-        // flight while the current pair is blended -- a 244-pixel strip is otherwise one dependent load -> blend -> store
-        // chain per thread and item (measured: latency, not arithmetic, bounded the blend)
-        const T *tiles[BLEND_MAXR];
-        int sy[BLEND_MAXR], sx[BLEND_MAXR];
-#pragma unroll
-        for (int k = 0; k < BLEND_MAXR; ++k) {
-            const Ref rf = P.refs[it.a + (k < nref ? k : 0)];
-            tiles[k] = tile_ptr<T>(P, plane, rf.tile);
-            sy[k] = rf.src_y + it.b;
-            sx[k] = rf.src_x + it.c;
-        }
-        auto load = [&](int r, int p0, u32x4 (&raw)[BLEND_MAXR]) {
-#pragma unroll
-            for (int k = 0; k < BLEND_MAXR; ++k)
-                if (k < nref) raw[k] = ldg<U32x4U>(tiles[k] + (int64_t)(sy[k] + r) * P.tile_pitch + sx[k] + p0);
-        };
-        const int total = rows * G;
-        int r = 0, p0 = 0;
-        OutT *dst = nullptr;
-        u32x4 raw[BLEND_MAXR];
-        int idx = tid;
-        bool have = idx < total && locate(idx, r, p0, dst);
-        if (have) load(r, p0, raw);
-        while (idx < total) {
-            const int nidx = idx + 256;
-            int nr = 0, np0 = 0;
-            OutT *ndst = nullptr;
-            u32x4 nraw[BLEND_MAXR];
-            const bool nhave = nidx < total && locate(nidx, nr, np0, ndst);
-            if (nhave) load(nr, np0, nraw);
-            if (have) blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, dst, raw);
-            idx = nidx;
-            have = nhave;
-            r = nr;
-            p0 = np0;
-            dst = ndst;
-#pragma unroll
-            for (int k = 0; k < BLEND_MAXR; ++k) raw[k] = nraw[k];
-        }
-    } else {
-        for (int idx = tid; idx < rows * G; idx += 256) {
-            int r, p0;
-            OutT *dst;
-            if (!locate(idx, r, p0, dst)) continue;
-            blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, dst);
-        }
+    // (A two-stage software pipeline over a thread's pairs -- the next pair's pixel vectors loaded before the current
+    // pair is blended -- was built and measured in round 2: 0.45-0.46 against 0.51-0.52 for this plain loop at equal item
+    // height, profiles/r02_exp9_feather.log: the second set of vectors costs the occupancy that hides the latency.)
+    for (int idx = tid; idx < rows * G; idx += 256) {
+        int r, p0;
+        OutT *dst;
+        if (!locate(idx, r, p0, dst)) continue;
+        blend_group<T, OutT, FLAT, FAST>(P, plane, it, flat, r, p0, dst);
     }
     for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
         const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;

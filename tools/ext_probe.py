@@ -31,7 +31,7 @@ ff = torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32)).to(dev)
 rho = g * g * T * T / (hc * wc)
 for dt, flats in ((torch.uint16, None), (torch.uint16, [ff] * P), (torch.float32, None)):
     canvas = native.empty_canvas(P, hc, wc, dt, dev)
-    t = timeit(lambda: native.fuse_planes(plan, tiles, canvas, flats))
+    t = timeit(lambda: native.fuse_planes(plan, tiles, canvas, flats, flags=int(os.environ.get('SQ_EXT_FLAGS', '0'))))
     alg = P * hc * wc * (2 * rho + canvas.element_size())       # 2*rho B read + the voxel written
     print(f'feather -> {dt}{" with float32 gains" if flats else ""}: {t*1e3:.2f} ms for {P} planes -> '
           f'{P*hc*wc/t/1e6:.0f} Mvoxel/s, {alg/t/1e9:.0f} GB/s algorithmic ({alg/t/8e12:.3f} of 8 TB/s)')
