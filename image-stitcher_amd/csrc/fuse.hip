@@ -1125,66 +1125,9 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
     }
 }
 
-// Feather mode, uint16 tiles and canvas, float32 gains: the plane groups of the overwrite kernel.  One-tile items (77 %
-// of the covered area at 244-pixel overlaps) go through process_item_zg<.., RND = 1> -- gains and their refined
-// reciprocals once per group, every bit of the result that of div_u16_normal_ieee + rint -- blended items plane by plane.
-template <bool DYN>
-__global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_feather_zg_kernel(const FuseParams P, const int64_t n_items) {
-    typedef uint16_t T;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const uint32_t n_groups = *P.n_groups;
-    auto pre = [&](int unit, const Item &it) -> UnitAux {
-        UnitAux A;
-        A.g = P.groups[unit];
-        A.a = A.b = A.c = A.pad = 0;
-        Ref rf{};
-        if (it.nref == 1) {
-            rf = P.refs[it.a];
-            A.a = rf.tile;
-            A.b = rf.src_y + it.b;
-            A.c = rf.src_x + it.c;
-        }
-#pragma unroll
-        for (int z = 0; z < ZB; ++z) A.tile[z] = (it.nref == 1 && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], rf.tile) : nullptr;
-        return A;
-    };
-    auto body = [&](int, const Item &it, const UnitAux &A) {
-        const int gn = sgpr(A.g.n);
-        if (it.nref <= 1) {
-            Item one = it;
-            one.a = sgpr(A.a);
-            one.b = sgpr(A.b);
-            one.c = sgpr(A.c);
-            if (gn == 1) process_item<T, 1, 1>(P, sgpr(A.g.plane[0]), one, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
-            else if (gn == ZB) process_item_zg<true, 1>(P, A, gn, one, wave, lane);
-            else process_item_zg<false, 1>(P, A, gn, one, wave, lane);
-            return;
-        }
-        for (int z = 0; z < gn; ++z) {
-            const int plane = sgpr(A.g.plane[z]);
-            if (P.flat_class[plane] == 0) blend_item<T, T, 1, true>(P, plane, it, threadIdx.x);
-            else blend_item<T, T, 1, false>(P, plane, it, threadIdx.x);
-        }
-    };
-    if (DYN) {
-        for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);
-    } else {
-        __shared__ Item s_it;
-        __shared__ UnitAux s_A;
-        const int64_t n_work = (int64_t)n_groups * n_items;
-        for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int unit = (int)(work / n_items);
-                s_it = P.items[work - unit * n_items];
-                s_A = pre(unit, s_it);
-            }
-            __syncthreads();
-            body(0, sgpr(s_it), s_A);
-        }
-    }
-}
+// (Plane groups for feather mode's one-tile items with gains -- process_item_zg<.., RND = 1> -- were built and measured in
+// round 2: 0.377-0.389 against 0.368 without them at equal item height, and slower than without at 32-row blend items
+// (profiles/r02_exp9_feather.log): the blended strips, two divides per output pixel, set that mode's time.  Not kept.)
 
 // Persistent launch: as many workgroups as the chip keeps resident (queried once per kernel),
 // each walking the (plane, item) list with a grid stride.
@@ -1489,17 +1432,6 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     const bool f32out = a->canvas_dtype == SQ_F32;
     if (!f32out && a->canvas_dtype != a->tile_dtype)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: feather canvas must be float32 or the tile dtype");
-    if (u16 && !f32out && flat == 1 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
-        char *sc = static_cast<char *>(a->scratch_dev);
-        uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
-        PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
-        hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, a->n_planes,
-                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
-        P.groups = groups;
-        P.n_groups = n_groups;
-        if (P.queue) return launch_zg(fuse_feather_zg_kernel<true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-        return launch_zg(fuse_feather_zg_kernel<false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-    }
 #define SQ_FEATHER_F(T, O, F)                                                                              \
     do {                                                                                                    \
         if (P.queue) return launch(fuse_feather_kernel<T, O, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);  \

@@ -311,7 +311,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             const Span &sp = spans[si];
             const Ref *rf = (mode == SQ_FUSE_OVERWRITE && sp.nref) ? &refs[sp.ref0] : nullptr;
             // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
-            // workgroup (fuse.hip blend_item): taller items there, so that a thread has a next pair to load ahead
+            // workgroup (fuse.hip blend_item): taller items there, two pairs per thread on a 244-pixel strip
             const int item_rows = (mode == SQ_FUSE_FEATHER && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
             for (int r0 = 0; r0 < sp.h; r0 += item_rows)
                 for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
