@@ -355,6 +355,21 @@ def run_region(ctx):
         out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas)
         out['cpu_baseline_reference'] = REFERENCE_TIMING
         out['parity'].update(check)
+    if world == 1 and args.workload is None and not args.planes and not os.environ.get('SQ_BENCH_NO_REFERENCE_JOB'):
+        # The N > 1 runs of this script measure the headline job (cfg4, strong scaling).  For the record, the SAME job on
+        # this one GPU (one step after one warm-up, ~3 s): the single-GPU point of that scaling curve, next to the config-3
+        # number above, which is this run's `value`.
+        del tiles, canvas, ptrs, flat_list, flat_ptrs, reg_plane
+        state.clear()
+        fuse_events.clear()
+        torch.cuda.empty_cache()
+        ref_args = argparse.Namespace(**dict(vars(args), steps=1, warmup=1, no_cpu_baseline=True, planes=0, batch=0, sha_out=None))
+        job = run_job(dict(ctx, args=ref_args, wl=dict(WORKLOADS['cfg4'], name='cfg4')))
+        out['headline_job_on_this_gpu'] = {
+            'workload': job['config']['workload'], 'value': job['value'], 'unit': job['unit'], 'ms_per_step': job['ms_per_step'],
+            'steps': 1, 'warmup': 1, 'scaling_note': 'the N = 1 point of the strong-scaling curve that bench.py --gpus N measures',
+            'resident_batches': job['config']['resident_batches_per_gpu'], 'roofline_frac': job['roofline']['frac'],
+            'launch_ms': job['roofline']['launch_ms']}
     return out
 
 
