@@ -249,3 +249,34 @@ def test_shifts_the_reference_cannot_place_fail_the_same_way(tmp_path):
     acq = O.parse_acquisition(root, read_image)
     with pytest.raises(ValueError, match=r"could not broadcast input array from shape \(61,70\) into shape \(61,0\)"):
         O.stitch_region(acq, 0, 'R0', read_image, True, dict(h_shift=(-9, 15), v_shift=(-14, -11)))
+
+
+def test_cli_with_ff_estimates_gains_on_the_device_and_says_so(tmp_path, capsys):
+    """`-r -ff` through the CLI without basicpy: the gains come from the device restatement of the BaSiC fit (parity with
+    basicpy unpinned, and the run says so on stdout, in flatfield_info.json and in shift_table.json); the canvas is the
+    oracle's for THOSE gains (the divide is exact whatever the gains are)."""
+    import json
+    from image_stitcher_amd.tiffio import read_image
+    from oracle import stitch_oracle as O
+    spec = synth.GridSpec(rows=3, cols=4, tile_h=128, tile_w=160, ov_y=36, ov_x=44, seed=77, channels=synth.DEFAULT_CHANNELS[:2])
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    params = StitchingParameters(input_folder=root, use_registration=True, apply_flatfield=True)
+    st = Stitcher(params, normalization='phase', flatfield_estimator='basic')
+    st.run()
+    out = capsys.readouterr().out
+    assert 'parity with it is unpinned' in out and st.flatfield_estimator_used == 'basic'
+    with open(os.path.join(st.output_folder, 'flatfield_info.json')) as fh:
+        info = json.load(fh)
+    assert info['estimator'] == 'basic' and sorted(info['channels']) == sorted(st.channel_names)
+    assert all(c['images'] == 12 and c['working_size'] == 128 and c['ladmap_iterations'] >= 1 for c in info['channels'].values())
+    with open(os.path.join(st.output_folder, 'shift_table.json')) as fh:
+        assert json.load(fh)['flatfield_estimator'] == 'basic'
+    assert sorted(st.flatfields) == [0, 1]
+    for ff in st.flatfields.values():
+        assert ff.shape == (128, 160) and ff.dtype == np.float32 and abs(float(ff.mean()) - 1.0) < 0.05 and np.isfinite(ff).all()
+    acq = O.parse_acquisition(root, read_image)
+    shifts = {'h_shift': tuple(st.h_shift), 'v_shift': tuple(st.v_shift)}
+    want = O.stitch_region(acq, 0, 'R0', read_image, True, shifts, st.flatfields, True)
+    store = os.path.join(st.output_folder, '0_stitched', 'R0_stitched.ome.zarr')
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), want)
