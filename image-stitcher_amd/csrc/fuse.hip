@@ -70,6 +70,10 @@ __device__ __forceinline__ void stg_nt(void *p, u32x4 v) {
     *(SQ_GLOBAL u32x4 *)p = v;
 #endif
 }
+// 16-byte non-temporal store at scalar base + 32-bit lane offset (bytes): no 64-bit address pair in vector registers
+__device__ __forceinline__ void stg_nt_at(void *base, uint32_t byte_off, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
 template <typename S>
 __device__ __forceinline__ void stg_s(void *p, S v) {
     *(SQ_GLOBAL S *)p = v;
@@ -728,36 +732,31 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
     for (int r = wave; r < rows; r += 4) {
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
         const int64_t soff = (int64_t)(it.b + r) * P.tile_pitch + it.c;
-        const float *frow = flat + (int64_t)(it.b + r) * P.tile_w + it.c;
-        // the phase of the row inside a 128-byte line: the same for every plane of the group (build_groups_kernel)
-        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (LINE - 1));
-        const int v_first = (mis + VEC - 1) / VEC, v_end = (n + mis) / VEC;
-        const int head_end = min(n, v_first * VEC - mis);
-        const int tail_start = max(head_end, v_end * VEC - mis);
-        int ep = -1;   // this lane's edge pixel: lanes 0..7 the head, 8..15 the tail
-        if (lane < VEC) {
-            if (lane < head_end) ep = lane;
-        } else if (lane < 2 * VEC) {
-            if (tail_start + (lane - VEC) < n) ep = tail_start + (lane - VEC);
-        }
-        const int epc = max(ep, 0);
-        const float eg = ldg_s<float>(frow + epc);
-        T e[ZB];
+        // row bases are wave-uniform (scalar registers); a lane adds ONE 32-bit byte offset, shared by the planes, so the
+        // loads and stores take the scalar-base + vector-offset form and no 64-bit address pair per plane lives in VGPRs
+        const char *frow = reinterpret_cast<const char *>(flat + (int64_t)(it.b + r) * P.tile_w + it.c);
+        const char *srow[ZB];
+        char *drow[ZB];
 #pragma unroll
-        for (int z = 0; z < ZB; ++z)
-            if (FULL || z < gn) e[z] = ldg_s<T>(tiles[z] + soff + epc);
+        for (int z = 0; z < ZB; ++z) {
+            srow[z] = reinterpret_cast<const char *>(tiles[z] + soff);
+            drow[z] = reinterpret_cast<char *>(cplane[z] + doff);
+        }
+        // the phase of the row inside a 128-byte line: the same for every plane of the group (build_groups_kernel)
+        const int mis = (int)((reinterpret_cast<uintptr_t>(drow[0]) / sizeof(T)) & (LINE - 1));
+        const int v_first = (mis + VEC - 1) / VEC, v_end = (n + mis) / VEC;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             if (64 * k >= v_end || v_end <= v_first) break;   // wave-uniform: no whole vector (left) in this row
             const int v = lane + 64 * k;
             const bool act = v >= v_first && v < v_end;
             const int p0 = v * VEC - mis;
-            const int p0c = min(max(p0, 0), n - VEC);          // v_end > v_first implies n >= VEC
-            const f32x4 g0 = ldg<F32x4U>(frow + p0c), g1 = ldg<F32x4U>(frow + p0c + 4);
+            const uint32_t o = (uint32_t)min(max(p0, 0), n - VEC);   // clamped: v_end > v_first implies n >= VEC; == p0 where act
+            const f32x4 g0 = ldg<F32x4U>(frow + o * 4u), g1 = ldg<F32x4U>(frow + o * 4u + 16u);
             u32x4 px[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
-                if (FULL || z < gn) px[z] = ldg<U32x4U>(tiles[z] + soff + p0c);
+                if (FULL || z < gn) px[z] = ldg<U32x4U>(srow[z] + o * 2u);
             f32x4 r0, r1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -767,21 +766,39 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    u32x4 o;
-                    o[0] = quot_pair<RND>(px[z][0], g0[0], g0[1], r0[0], r0[1]);
-                    o[1] = quot_pair<RND>(px[z][1], g0[2], g0[3], r0[2], r0[3]);
-                    o[2] = quot_pair<RND>(px[z][2], g1[0], g1[1], r1[0], r1[1]);
-                    o[3] = quot_pair<RND>(px[z][3], g1[2], g1[3], r1[2], r1[3]);
-                    if (act) stg_nt(cplane[z] + doff + p0, o);
+                    u32x4 ov;
+                    ov[0] = quot_pair<RND>(px[z][0], g0[0], g0[1], r0[0], r0[1]);
+                    ov[1] = quot_pair<RND>(px[z][1], g0[2], g0[3], r0[2], r0[3]);
+                    ov[2] = quot_pair<RND>(px[z][2], g1[0], g1[1], r1[0], r1[1]);
+                    ov[3] = quot_pair<RND>(px[z][3], g1[2], g1[3], r1[2], r1[3]);
+                    if (act) stg_nt_at(drow[z], o * 2u, ov);
                 }
         }
-        const float er = recip_for<RND>(eg);
+        // the row's edges (canvas pixels before the first / after the last whole 16-byte vector): lanes 0..7 the head,
+        // 8..15 the tail, one pixel each -- after the vectors, so that nothing of them lives across the slot loop
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int ep = -1;
+        if (lane < VEC) {
+            if (lane < head_end) ep = lane;
+        } else if (lane < 2 * VEC) {
+            if (tail_start + (lane - VEC) < n) ep = tail_start + (lane - VEC);
+        }
+        if (__builtin_amdgcn_ballot_w64(ep >= 0)) {   // wave-uniform: many rows have no edge pixels at all
+            const uint32_t eo = (uint32_t)max(ep, 0);
+            const float eg = ldg_s<float>(frow + eo * 4u);
+            T e[ZB];
 #pragma unroll
-        for (int z = 0; z < ZB; ++z)
-            if (FULL || z < gn) {
-                const uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
-                if (ep >= 0) stg_s<T>(cplane[z] + doff + ep, (T)kq);
-            }
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) e[z] = ldg_s<T>(srow[z] + eo * 2u);
+            const float er = recip_for<RND>(eg);
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    const uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
+                    if (ep >= 0) stg_s<T>(drow[z] + eo * 2u, (T)kq);
+                }
+        }
     }
 }
 
@@ -807,6 +824,9 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
     };
     auto body = [&](int, const Item &it, const UnitAux &A) {
         const int gn = sgpr(A.g.n);
+#ifdef SQ_ZG_FULL_ONLY     /* experiment: full groups only (plane counts that are multiples of ZB) */
+        if (gn == ZB) process_item_zg<true>(P, A, gn, it, wave, lane);
+#else
         if (gn == 1) {
             process_item<T, 1>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
         } else if (gn == ZB) {
@@ -814,6 +834,7 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
         } else {
             process_item_zg<false>(P, A, gn, it, wave, lane);
         }
+#endif
     };
     if (DYN) {
         for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);

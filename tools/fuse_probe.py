@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
     ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
     ap.add_argument('--flags', type=int, default=0)
+    ap.add_argument('--canvas-first', action='store_true', help='allocate the canvas before the tiles')
     ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -37,6 +38,8 @@ def main():
     print(f'plan: {plan.n_spans} spans, {plan.n_items} items, table {plan.table.nbytes/1e6:.2f} MB, '
           f'{time.time()-t0:.3f}s; canvas {hc}x{wc}; covered {plan.covered_voxels/(hc*wc):.3f}')
     spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=a.ov, ov_x=a.ov, seed=1)
+    early = (native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else
+             torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)) if a.canvas_first else None
     tiles = torch.empty((a.planes, g * g, T, T), dtype=torch.uint16, device=dev)
     for p in range(a.planes):
         desc = np.zeros(g * g, dtype=native.SYNTH_DTYPE)
@@ -46,8 +49,9 @@ def main():
                 desc[r * g + c] = (spec.scene_seed(0, 0, p, 0) % 2**64, spec.noise_seed(0, 0, p, 0, r * g + c) % 2**64, oy, ox)
         native.synth_tiles(desc, T, T, 200, 'uint16', dev, out=tiles[p])
     torch.cuda.synchronize()
-    canvas = native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else \
-        torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)
+    canvas = early if early is not None else (native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else
+                                              torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev))
+    print(f'tiles at {tiles.data_ptr():#x}, canvas at {canvas.data_ptr():#x}')
     flats = None
     if a.flat != 'none':
         g = synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)
