@@ -507,11 +507,15 @@ def run_job(ctx):
             sh = registration.register_grid_center(reg_tiles, g, g, xs, ys, spec.pixel_size_um, spec.pixel_binning,
                                                    normalization='phase', tile_index=lambda r, c: reg_index[(r, c)])
             row = sharding.shifts_to_row(sh)
+        t1 = time.perf_counter()
         shifts = sharding.first_valid(sharding.all_gather_shift_table(row[None], device=coll_dev))   # RCCL
+        t2 = time.perf_counter()
         plan = plan_for(shifts)
         torch.cuda.synchronize()
-        timed += time.perf_counter() - t0
-        lap['register+allgather+plan'] = lap.get('register+allgather+plan', 0.0) + (time.perf_counter() - t0)
+        t3 = time.perf_counter()
+        timed += t3 - t0
+        for k, v in (('register', t1 - t0), ('allgather', t2 - t1), ('plan', t3 - t2)):
+            lap.setdefault(k, []).append(v)
         for bi, b in enumerate(batches):
             for k, p in enumerate(b):      # this batch's tiles -> HBM (not timed: inputs are resident when timing starts)
                 native.synth_tiles(descs[p], TILE, TILE, spec.noise, 'uint16', dev, out=tiles[k])
@@ -582,9 +586,8 @@ def run_job(ctx):
         'parity': shift_parity(shifts, truth),
     }
     if rank == 0 and os.environ.get('SQ_BENCH_BREAKDOWN'):
-        n = args.steps + args.warmup
-        print(f'[bench] rank 0 timed {mine_s / args.steps * 1e3:.2f} ms/job; host ms per job: ' +
-              ', '.join(f'{k} {v / n * 1e3:.2f}' for k, v in lap.items()), file=sys.stderr)
+        print(f'[bench] rank 0 timed {mine_s / args.steps * 1e3:.2f} ms/job; host ms per job (every job, warm-up first): ' +
+              '; '.join(f'{k} ' + ' '.join(f'{x * 1e3:.2f}' for x in v) for k, v in lap.items()), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the last batch is still resident: the oracle on a bounded sample of it (2 planes of the 32x32 grid)
         b = batches[-1]

@@ -53,8 +53,9 @@ struct TableHeader {
     int64_t off_spans, off_refs, off_items;  // byte offsets from the table start
     int64_t covered_voxels;
     int64_t lane_items;   // list positions [0, 8 * lane_items) are lane-interleaved: position = rank * 8 + lane (else 0)
+    int64_t off_seams;    // n_items Seam records, item order (overwrite plans; 0: none)
 };
-static_assert(sizeof(TableHeader) == 96, "TableHeader layout");
+static_assert(sizeof(TableHeader) == 104, "TableHeader layout");
 
 struct Span {
     int32_t dst_y, dst_x, h, w;
@@ -82,6 +83,26 @@ struct Item {
     int32_t span;
 };
 static_assert(sizeof(Item) == 32, "Item layout");
+
+// Who writes the 128-byte canvas line a vertical seam falls in (overwrite plans).  Two items that meet at a seam
+// (same canvas rows, both at least SEAM_MIN_COLS wide) would each write their part of that line: two partial-line
+// writes, measured 4 % of the whole launch (tools/membw.hip "2d", profiles/r02_membw_2d.log).  Instead the RIGHT
+// item writes the whole line -- its own pixels and, from the left item's source, the pixels before its first --
+// and the left item stops at the line boundary.  Which pixels that is depends on the address of the row (canvas
+// pitch and base), so it is worked out per row on the device; the plan only says who owns the seam.
+//   flags & SEAM_HAS_LEFT  : this item also writes the pixels between the line boundary and its dst_x, taken from
+//                            tile `a` (row b + r, columns ending at c: the pixel at dst_x - j is column c - j), or
+//                            zeros with SEAM_LEFT_ZERO
+//   flags & SEAM_LEAVE_TAIL: the line this item's last pixel falls in belongs to its right neighbour, unless the
+//                            item ends exactly on a line boundary
+// A kernel either honours the flags for every item of a plane or for none (both are a partition of the canvas).
+constexpr int SEAM_MIN_COLS = 64;      // one line of uint16: head line and tail line of an item are then distinct
+enum : int32_t { SEAM_HAS_LEFT = 1, SEAM_LEAVE_TAIL = 2, SEAM_LEFT_ZERO = 4 };
+struct Seam {
+    int32_t a, b, c;
+    int32_t flags;
+};
+static_assert(sizeof(Seam) == 16, "Seam layout");
 
 }  // namespace sq
 

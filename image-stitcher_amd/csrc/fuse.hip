@@ -83,6 +83,7 @@ struct FuseParams {
     const Span *spans;
     const Ref *refs;
     const Item *items;
+    const Seam *seams;            // per item, who writes the canvas line a vertical seam falls in (overwrite plans), or NULL
     const void *const *tile_ptrs;
     const void *tile_base;
     int64_t tile_plane_stride, tile_stride;
@@ -426,13 +427,18 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
 }
 
 template <typename T>
-__device__ __forceinline__ void row_zero(T *drow, int n, int lane) {
+__device__ __forceinline__ void row_zero(T *drow, int n, int lane, bool leave_tail = false) {
     constexpr int VEC = Pix<T>::N;
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
     Row<T> J;
     J.drow = drow;
     J.n = n;
     row_setup<T>(J, lane);
+    if (leave_tail) {   // the line the row ends in is written by the right neighbour (Seam in common.h; n >= one line)
+        constexpr int LINE = 128 / (int)sizeof(T);
+        J.v_end = (n - ((n + J.mis) & (LINE - 1)) + J.mis) / VEC;
+        if (lane >= VEC) J.edge_p = -1;
+    }
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int v = lane + 64 * k;
@@ -557,7 +563,7 @@ __device__ __forceinline__ const T *sgpr(const T *p) {
 
 // The queue walk shared by the fusion kernels: calls body(plane, item, aux) for every (plane, item) this
 // workgroup is handed, all threads of the workgroup together, arguments in scalar registers.
-// aux = pre(plane, item) is evaluated by the thread that loads the descriptor (the overwrite kernel
+// aux = pre(plane, item, list position) is evaluated by the thread that loads the descriptor (the overwrite kernel
 // fetches the tile pointer there, so that eight of them are in flight at once).
 template <typename Aux, typename Pre, typename Body>
 __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const int64_t n_items, const uint32_t n_units, Pre pre,
@@ -601,10 +607,11 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
             const uint32_t u = u0 + threadIdx.x;
             const int plane = (int)(u / per_plane);
             const uint32_t r = u - (uint32_t)plane * per_plane;
-            const Item it = P.items[q < 8 ? (int64_t)r * 8 + q : 8 * (int64_t)P.lane_items + r];
+            const int64_t pos = q < 8 ? (int64_t)r * 8 + q : 8 * (int64_t)P.lane_items + r;
+            const Item it = P.items[pos];
             s_item[threadIdx.x] = it;
             s_plane[threadIdx.x] = plane;
-            s_aux[threadIdx.x] = pre(plane, it);
+            s_aux[threadIdx.x] = pre(plane, it, pos);
         }
         __syncthreads();
         for (int j = 0; j < count; ++j) body(sgpr(s_plane[j]), sgpr(s_item[j]), s_aux[j]);
@@ -652,7 +659,7 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
     }
     for_each_queued_item<const void *>(
         P, n_items, (uint32_t)P.n_planes,
-        [&](int plane, const Item &it) -> const void * { return it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr; },
+        [&](int plane, const Item &it, int64_t) -> const void * { return it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr; },
         [&](int plane, const Item &it, const void *const &tile) {
             process_item<T, FLAT>(P, plane, it, sgpr(static_cast<const T *>(tile)), wave, lane);
         });
@@ -676,7 +683,8 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
 struct UnitAux {
     PlaneGroup g;
     const void *tile[ZB];
-    int32_t a, b, c, pad;   // feather: tile index and source origin of a one-tile item (looked up through its Ref)
+    const void *ltile[ZB];  // the planes' tiles left of the seam this item owns (Seam in common.h)
+    Seam seam;
 };
 
 // RND = 0 (overwrite: truncate): Markstein with r = v_rcp_f32(g), the arithmetic of div_u16_normal.
@@ -712,6 +720,8 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
     constexpr int VEC = 8, LINE = 64;
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    const int sflags = sgpr(A.seam.flags);
+    const bool leave_tail = sflags & SEAM_LEAVE_TAIL;
     T *cplane[ZB];
     const T *tiles[ZB];
 #pragma unroll
@@ -721,11 +731,37 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         tiles[z] = sgpr(static_cast<const T *>(A.tile[zz]));
     }
     if (!it.nref) {   // uncovered canvas: zeros (da.zeros, stitcher.py:362)
+        const bool has_left = sflags & SEAM_HAS_LEFT, lzero = sflags & SEAM_LEFT_ZERO;
+        for (int r = wave; r < rows; r += 4) {
+            const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (LINE - 1));
+            const int head = (has_left && mis > 0) ? mis : 0;   // pixels of the left neighbour in the seam's line
+            if (head && !lzero) {   // the seam's line: the left tile's pixels, then zeros (see head_line below)
+                const int p = lane - mis;
+                const bool left = p < 0;
+                const int po = left ? p : -1;
+                const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
+                const float *lflat = static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+                const float eg = ldg_s<float>(reinterpret_cast<const char *>(lflat + (int64_t)(sb + r) * P.tile_w + sc) + po * 4);
+                const float er = recip_for<RND>(eg);
 #pragma unroll
-        for (int z = 0; z < ZB; ++z)
-            if (FULL || z < gn)
-                for (int r = wave; r < rows; r += 4)
-                    row_zero<T>(cplane[z] + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
+                for (int z = 0; z < ZB; ++z)
+                    if (FULL || z < gn) {
+                        const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
+                        const T e = ldg_s<T>(reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc) + po * 2);
+                        const uint32_t kq = left ? min(cvt_u32_sat(quot_one<RND>((float)e, eg, er)), 65535u) : 0u;
+                        stg_s<T>(reinterpret_cast<char *>(cplane[z] + doff) + p * 2, (T)kq);
+                    }
+            }
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    T *d = cplane[z] + doff;
+                    if (head && lzero) row_zero<T>(d - head, n + head, lane, leave_tail);                // zeros from the line boundary
+                    else if (head) row_zero<T>(d + (LINE - head), n - (LINE - head), lane, leave_tail);    // after the seam's line
+                    else row_zero<T>(d, n, lane, leave_tail);
+                }
+        }
         return;
     }
     const float *flat = static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
@@ -744,7 +780,11 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         }
         // the phase of the row inside a 128-byte line: the same for every plane of the group (build_groups_kernel)
         const int mis = (int)((reinterpret_cast<uintptr_t>(drow[0]) / sizeof(T)) & (LINE - 1));
-        const int v_first = (mis + VEC - 1) / VEC, v_end = (n + mis) / VEC;
+        // seams (common.h): with head_line this item writes the whole line its first pixel falls in (below, after the
+        // vectors); with leave_tail it stops at the last line boundary and the right neighbour writes the rest
+        const bool head_line = (sflags & SEAM_HAS_LEFT) && mis > 0;
+        const int n_own = leave_tail ? n - ((n + mis) & (LINE - 1)) : n;   // n >= LINE where a flag is set
+        const int v_first = head_line ? LINE / VEC : (mis + VEC - 1) / VEC, v_end = (n_own + mis) / VEC;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             if (64 * k >= v_end || v_end <= v_first) break;   // wave-uniform: no whole vector (left) in this row
@@ -774,15 +814,42 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                     if (act) stg_nt_at(drow[z], o * 2u, ov);
                 }
         }
-        // the row's edges (canvas pixels before the first / after the last whole 16-byte vector): lanes 0..7 the head,
-        // 8..15 the tail, one pixel each -- after the vectors, so that nothing of them lives across the slot loop
-        const int head_end = min(n, v_first * VEC - mis);
+        if (head_line) {
+            // the seam's line, one pixel per lane: lane j writes byte 2j of the line, the pixels before dst_x from the
+            // left neighbour's tile (or zero fill), the rest from this item's -- one whole-line store per plane
+            const int p = lane - mis;   // pixel relative to dst_x: -mis .. 63 - mis (< n)
+            const bool left = p < 0, lzero = sflags & SEAM_LEFT_ZERO;
+            const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
+            const int po = (left && lzero) ? 0 : p;   // left of a zero-fill seam: any valid address, the value is replaced
+            const char *lfrow = lzero ? frow : reinterpret_cast<const char *>(flat + (int64_t)(sb + r) * P.tile_w + sc);
+            const float eg = ldg_s<float>((left ? lfrow : frow) + po * 4);
+            T e[ZB];
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
+                    const char *lrow = lzero ? srow[z] : reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc);
+                    e[z] = ldg_s<T>((left ? lrow : srow[z]) + po * 2);
+                }
+            const float er = recip_for<RND>(eg);
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
+                    if (left && lzero) kq = 0;
+                    stg_s<T>(drow[z] + p * 2, (T)kq);
+                }
+        }
+        // the row's other edges (canvas pixels before the first / after the last whole 16-byte vector that no seam line
+        // covers): lanes 0..7 the head, 8..15 the tail, one pixel each -- after the vectors, so that nothing of them lives
+        // across the slot loop
+        const int head_end = head_line ? 0 : min(n_own, v_first * VEC - mis);
         const int tail_start = max(head_end, v_end * VEC - mis);
         int ep = -1;
         if (lane < VEC) {
             if (lane < head_end) ep = lane;
         } else if (lane < 2 * VEC) {
-            if (tail_start + (lane - VEC) < n) ep = tail_start + (lane - VEC);
+            if (tail_start + (lane - VEC) < n_own) ep = tail_start + (lane - VEC);
         }
         if (__builtin_amdgcn_ballot_w64(ep >= 0)) {   // wave-uniform: many rows have no edge pixels at all
             const uint32_t eo = (uint32_t)max(ep, 0);
@@ -811,15 +878,16 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = *P.n_groups;
-    auto pre = [&](int unit, const Item &it) -> UnitAux {
+    auto pre = [&](int unit, const Item &it, int64_t pos) -> UnitAux {
         UnitAux A;
         A.g = P.groups[unit];
+        A.seam = P.seams ? P.seams[pos] : Seam{-1, 0, 0, 0};
+        const bool left_tile = (A.seam.flags & SEAM_HAS_LEFT) && !(A.seam.flags & SEAM_LEFT_ZERO);
 #pragma unroll
-        for (int z = 0; z < ZB; ++z) A.tile[z] = (it.nref && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], it.a) : nullptr;
-        A.a = it.a;
-        A.b = it.b;
-        A.c = it.c;
-        A.pad = 0;
+        for (int z = 0; z < ZB; ++z) {
+            A.tile[z] = (it.nref && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], it.a) : nullptr;
+            A.ltile[z] = (left_tile && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], A.seam.a) : nullptr;
+        }
         return A;
     };
     auto body = [&](int, const Item &it, const UnitAux &A) {
@@ -847,7 +915,7 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
             if (threadIdx.x == 0) {
                 const int unit = (int)(work / n_items);
                 s_it = P.items[work - unit * n_items];
-                s_A = pre(unit, s_it);
+                s_A = pre(unit, s_it, work - unit * n_items);
             }
             __syncthreads();
             body(0, sgpr(s_it), s_A);
@@ -1136,7 +1204,7 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
     if (DYN) {
         // single-tile and blended items cost very differently: the queues (one "rest" queue here, the
         // feather plan is not lane-interleaved) keep every workgroup busy until the end
-        for_each_queued_item<int>(P, n_items, (uint32_t)P.n_planes, [](int, const Item &) -> int { return 0; },
+        for_each_queued_item<int>(P, n_items, (uint32_t)P.n_planes, [](int, const Item &, int64_t) -> int { return 0; },
                                   [&](int plane, const Item &it, const int &) { one_item(plane, it); });
     } else {
         for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
@@ -1355,7 +1423,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
     if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
-    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS)) || a->grid_blocks < 0 ||
+    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS | SQ_FUSE_NO_SEAM_OWNERS)) || a->grid_blocks < 0 ||
         ((a->flags & SQ_FUSE_FORCE_QUEUES) && (a->flags & SQ_FUSE_FORCE_STATIC)))
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: flags %d / grid_blocks %d", a->flags, a->grid_blocks);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
@@ -1373,6 +1441,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.spans = reinterpret_cast<const Span *>(base + h.off_spans);
     P.refs = reinterpret_cast<const Ref *>(base + h.off_refs);
     P.items = reinterpret_cast<const Item *>(base + h.off_items);
+    P.seams = (h.off_seams && !(a->flags & SQ_FUSE_NO_SEAM_OWNERS)) ? reinterpret_cast<const Seam *>(base + h.off_seams) : nullptr;
     P.tile_ptrs = a->tile_ptrs_dev;
     P.tile_base = a->tile_base_dev;
     P.tile_plane_stride = a->tile_plane_stride;

@@ -305,45 +305,87 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     if (bands)
         std::stable_sort(span_order.begin(), span_order.end(),
                          [&](size_t a, size_t b) { return spans[a].dst_x < spans[b].dst_x; });
-    auto for_each_item = [&](auto &&emit) {
-        for (size_t so = 0; so < spans.size(); ++so) {
-            const size_t si = span_order[so];
-            const Span &sp = spans[si];
-            const Ref *rf = (mode == SQ_FUSE_OVERWRITE && sp.nref) ? &refs[sp.ref0] : nullptr;
-            // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
-            // workgroup (fuse.hip blend_item): taller items there, two pairs per thread on a 244-pixel strip
-            const int item_rows = (mode == SQ_FUSE_FEATHER && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
-            for (int r0 = 0; r0 < sp.h; r0 += item_rows)
-                for (int c0 = 0; c0 < sp.w; c0 += BLOCK_COLS) {
-                    Item it;
-                    it.dst_y = sp.dst_y + r0;
-                    it.dst_x = sp.dst_x + c0;
-                    it.hw = (std::min(item_rows, sp.h - r0) << 16) | std::min(BLOCK_COLS, sp.w - c0);
-                    it.nref = sp.nref;
-                    it.span = (int32_t)si;
-                    if (mode == SQ_FUSE_OVERWRITE) {
-                        it.a = rf ? rf->tile : -1;
-                        it.b = rf ? rf->src_y + r0 : 0;
-                        it.c = rf ? rf->src_x + c0 : 0;
-                    } else {
-                        it.a = sp.ref0;
-                        it.b = r0;
-                        it.c = c0;
-                    }
-                    emit(it);
+    // Overwrite plans cut rows on the canvas' own grid of BLOCK_ROWS rows (not from the top of each span), so that
+    // the items either side of a vertical seam cover the same rows and the seam can be given one owner (Seam in
+    // common.h); a column remainder narrower than a line is widened at the expense of the piece before it.
+    std::vector<Item> items;
+    items.reserve(spans.size() * 4);
+    for (size_t so = 0; so < spans.size(); ++so) {
+        const size_t si = span_order[so];
+        const Span &sp = spans[si];
+        const bool ow = mode == SQ_FUSE_OVERWRITE;
+        const Ref *rf = (ow && sp.nref) ? &refs[sp.ref0] : nullptr;
+        // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
+        // workgroup (fuse.hip blend_item): taller items there, two pairs per thread on a 244-pixel strip
+        const int item_rows = (!ow && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
+        for (int r0 = 0; r0 < sp.h;) {
+            const int rows = std::min(ow ? item_rows - (sp.dst_y + r0) % item_rows : item_rows, sp.h - r0);
+            for (int c0 = 0; c0 < sp.w;) {
+                int cols = std::min(BLOCK_COLS, sp.w - c0);
+                const int rest = sp.w - c0 - cols;
+                if (ow && rest > 0 && rest < SEAM_MIN_COLS) cols -= SEAM_MIN_COLS;
+                Item it;
+                it.dst_y = sp.dst_y + r0;
+                it.dst_x = sp.dst_x + c0;
+                it.hw = (rows << 16) | cols;
+                it.nref = sp.nref;
+                it.span = (int32_t)si;
+                if (ow) {
+                    it.a = rf ? rf->tile : -1;
+                    it.b = rf ? rf->src_y + r0 : 0;
+                    it.c = rf ? rf->src_x + c0 : 0;
+                } else {
+                    it.a = sp.ref0;
+                    it.b = r0;
+                    it.c = c0;
                 }
+                items.push_back(it);
+                c0 += cols;
+            }
+            r0 += rows;
         }
-    };
+    }
+    const int64_t n_items = (int64_t)items.size();
+
+    // seam owners: item J takes the seam on its left when the item I that ends where J begins covers the same rows
+    // and both are at least a line wide (tile or zero fill, either side)
+    std::vector<Seam> seams;
+    if (mode == SQ_FUSE_OVERWRITE) {
+        seams.assign(items.size(), Seam{-1, 0, 0, 0});
+        const int nb = canvas_h / BLOCK_ROWS + 1;
+        std::vector<int32_t> first(nb + 1, 0), by_band(items.size());
+        for (const Item &it : items) ++first[it.dst_y / BLOCK_ROWS + 1];
+        for (int k = 0; k < nb; ++k) first[k + 1] += first[k];
+        {
+            std::vector<int32_t> at(first.begin(), first.end() - 1);
+            for (size_t i = 0; i < items.size(); ++i) by_band[at[items[i].dst_y / BLOCK_ROWS]++] = (int32_t)i;
+        }
+        for (size_t j = 0; j < items.size(); ++j) {
+            const Item &J = items[j];
+            if ((J.hw & 0xFFFF) < SEAM_MIN_COLS || J.dst_x == 0) continue;
+            const int k = J.dst_y / BLOCK_ROWS;
+            for (int32_t q = first[k]; q < first[k + 1]; ++q) {
+                const Item &I = items[by_band[q]];
+                const int in = I.hw & 0xFFFF;
+                if (I.dst_x + in != J.dst_x || I.dst_y != J.dst_y || (I.hw >> 16) != (J.hw >> 16)) continue;
+                if (in >= SEAM_MIN_COLS) {
+                    seams[j].a = I.a;
+                    seams[j].b = I.b;
+                    seams[j].c = I.c + in;
+                    seams[j].flags |= SEAM_HAS_LEFT | (I.nref ? 0 : SEAM_LEFT_ZERO);
+                    seams[by_band[q]].flags |= SEAM_LEAVE_TAIL;
+                }
+                break;
+            }
+        }
+    }
+
     auto key_of = [&](const Item &it) {
         if (bands) return std::min(it.dst_y / BLOCK_ROWS, nblk - 2);
         return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1;
     };
     std::vector<int64_t> count(nblk, 0);
-    int64_t n_items = 0;
-    for_each_item([&](const Item &it) {
-        ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4) ? key_of(it) : 0];
-        ++n_items;
-    });
+    for (const Item &it : items) ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4) ? key_of(it) : 0];
     const auto t_items = std::chrono::steady_clock::now();
 
     auto *plan = new sq_fuse_plan;
@@ -363,7 +405,8 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     hd.off_refs = hd.off_spans + hd.n_spans * (int64_t)sizeof(Span);
     hd.off_items = hd.off_refs + hd.n_refs * (int64_t)sizeof(Ref);
     hd.covered_voxels = covered;
-    const int64_t total = hd.off_items + hd.n_items * (int64_t)sizeof(Item);
+    hd.off_seams = seams.empty() ? 0 : hd.off_items + hd.n_items * (int64_t)sizeof(Item);
+    const int64_t total = hd.off_items + hd.n_items * (int64_t)sizeof(Item) + (int64_t)(seams.size() * sizeof(Seam));
     if (!plan->table.allocate((size_t)total)) {
         delete plan;
         fail(SQ_ERR_INVALID, "sq_fuse_plan_create: out of host memory for a %lld-byte table", (long long)total);
@@ -374,17 +417,22 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     if (!spans.empty()) std::memcpy(p + hd.off_spans, spans.data(), spans.size() * sizeof(Span));
     if (!refs.empty()) std::memcpy(p + hd.off_refs, refs.data(), refs.size() * sizeof(Ref));
     Item *dst = reinterpret_cast<Item *>(p + hd.off_items);
+    Seam *dst_seam = seams.empty() ? nullptr : reinterpret_cast<Seam *>(p + hd.off_seams);
+    auto place = [&](int64_t pos, size_t i) {
+        dst[pos] = items[i];
+        if (dst_seam) dst_seam[pos] = seams[i];
+    };
     if (order_mode == 0) {
-        int64_t i = 0;
-        for_each_item([&](const Item &it) { dst[i++] = it; });
+        for (size_t i = 0; i < items.size(); ++i) place((int64_t)i, i);
     } else if (order_mode == 3) {
         // canvas raster order: bands of BLOCK_ROWS canvas rows, left to right; zero-fill items in place
-        int64_t i = 0;
-        for_each_item([&](const Item &it) { dst[i++] = it; });
-        std::stable_sort(dst, dst + n_items, [](const Item &a, const Item &b) {
-            const int ba = a.dst_y / BLOCK_ROWS, bb = b.dst_y / BLOCK_ROWS;
-            return ba != bb ? ba < bb : a.dst_x < b.dst_x;
+        std::vector<size_t> idx(items.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+            const int ba = items[a].dst_y / BLOCK_ROWS, bb = items[b].dst_y / BLOCK_ROWS;
+            return ba != bb ? ba < bb : items[a].dst_x < items[b].dst_x;
         });
+        for (size_t i = 0; i < idx.size(); ++i) place((int64_t)i, idx[i]);
     } else {
         // position of the k-th item of bucket `key` in the row-block-sorted list ...
         std::vector<int64_t> start(nblk + 1, 0);
@@ -408,8 +456,8 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             std::memcpy(plan->table.ptr, &hd, sizeof hd);
         }
         std::vector<int64_t> seen(nblk, 0);
-        for_each_item([&](const Item &it) {
-            const int k = key_of(it);
+        for (size_t i = 0; i < items.size(); ++i) {
+            const int k = key_of(items[i]);
             const int64_t j = seen[k]++;
             int64_t pos;
             if (k == nblk - 1 || order_mode == 1) {
@@ -419,8 +467,8 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 const int64_t t = lane_base[k] + j;
                 pos = t < common ? t * NX + x : tail_at[x] + (t - common);
             }
-            dst[pos] = it;
-        });
+            place(pos, i);
+        }
     }
     const auto t_order = std::chrono::steady_clock::now();
     const size_t n_spans_dbg = spans.size();

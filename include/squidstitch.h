@@ -126,7 +126,8 @@ typedef struct sq_fuse_args {
 typedef enum sq_fuse_flags {
     SQ_FUSE_FORCE_QUEUES = 1, /* device work queues whatever the launch size (needs scratch_dev) */
     SQ_FUSE_FORCE_STATIC = 2, /* static grid-stride walk whatever the launch size                */
-    SQ_FUSE_NO_PLANE_GROUPS = 4 /* uint16 / float32 gains: one plane at a time even where planes share a gain image */
+    SQ_FUSE_NO_PLANE_GROUPS = 4, /* uint16 / float32 gains: one plane at a time even where planes share a gain image */
+    SQ_FUSE_NO_SEAM_OWNERS = 8   /* plane groups: both items at a vertical seam write their part of the shared cache line */
 } sq_fuse_flags;
 
 int64_t sq_fuse_scratch_bytes(int32_t n_planes);

@@ -455,3 +455,51 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
             O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, g, out_dtype=np.uint16)
         np.testing.assert_array_equal(aligned[p].cpu().numpy(), want, err_msg=f'plane {p} (gain image {which[p]}) of {planes}')
         np.testing.assert_array_equal(dense[p].cpu().numpy(), want, err_msg=f'dense plane {p}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('queues', [False, True], ids=['static', 'queues'])
+@pytest.mark.parametrize('seed', range(5))
+def test_seam_lines_have_one_writer(seed, queues):
+    """Plane groups, tiles at least a cache line wide either side of every vertical seam: the item right of a seam writes
+    the whole 128-byte line the seam falls in (pixels of BOTH tiles, or zero fill on the left), the item left of it stops
+    at the line boundary (Seam in csrc/common.h).  Canvas pitches that put every row at a different phase, pitches that
+    are multiples of a line, a base address off the line grid: every plane equals the oracle, and the canvas padding
+    between rows and between planes keeps its poison."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5200 + seed)
+    th, tw = int(rng.integers(12, 40)), int(rng.integers(150, 420))
+    gr, gc = int(rng.integers(1, 4)), int(rng.integers(2, 5))
+    rects = []
+    x_margin = int(rng.integers(0, 2)) * int(rng.integers(64, 100))     # sometimes zero fill a line wide on the LEFT too
+    for r in range(gr):
+        for c in range(gc):
+            left = int(rng.integers(0, 40)) if c else 0
+            top = int(rng.integers(0, 6)) if r else 0
+            rects.append((top, left, th - top, tw - left - int(rng.integers(0, 30)),
+                          r * (th - 8) + int(rng.integers(0, 5)) + top, x_margin + c * (tw - 70) + int(rng.integers(0, 9)) + left))
+    rects = np.array(rects)
+    ch = int((rects[:, 4] + rects[:, 2]).max()) + int(rng.integers(0, 5))
+    cw = int((rects[:, 5] + rects[:, 3]).max()) + int(rng.integers(0, 140))
+    planes = int(rng.integers(2, 8))
+    tiles = rng.integers(0, 65536, size=(planes, len(rects), th, tw)).astype(np.uint16)
+    gain = np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float32)
+    d_gain = torch.from_numpy(gain).to(dev)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    plan = native.FusePlan(rects, th, tw, ch, cw)
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    want = [O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, gain) for p in range(planes)]
+    for pitch, lead in ((cw, 0), (cw + 1, 0), (-(-cw // 64) * 64, 0), (cw + 37, 64 * 3), (cw + 2, 64 * 5 + 13)):
+        stride = -(-(ch * pitch) // 64) * 64                 # planes a multiple of 128 bytes apart: groups form
+        buf = torch.full((lead + planes * stride + 64,), 0x5A5A, dtype=torch.uint16, device=dev)
+        canvas = buf[lead:].as_strided((planes, ch, cw), (stride, pitch, 1))
+        native.fuse_planes(plan, d_tiles, canvas, [d_gain] * planes, flags=flags)
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        for p in range(planes):
+            got = host[lead + p * stride: lead + p * stride + ch * pitch].reshape(ch, pitch)
+            np.testing.assert_array_equal(got[:, :cw], want[p], err_msg=f'plane {p}, pitch {pitch}')
+            assert (got[:, cw:] == 0x5A5A).all(), f'row padding of plane {p} touched (pitch {pitch})'
+            assert (host[lead + p * stride + ch * pitch: lead + (p + 1) * stride] == 0x5A5A).all()
+        assert (host[:lead] == 0x5A5A).all() and (host[lead + planes * stride:] == 0x5A5A).all()

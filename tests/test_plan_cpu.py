@@ -15,12 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = np.dtype([('magic', '<u4'), ('mode', '<i4'), ('canvas_h', '<i4'), ('canvas_w', '<i4'), ('tile_h', '<i4'),
                 ('tile_w', '<i4'), ('n_tiles', '<i4'), ('max_refs', '<i4'), ('n_spans', '<i8'), ('n_refs', '<i8'),
                 ('n_items', '<i8'), ('off_spans', '<i8'), ('off_refs', '<i8'), ('off_items', '<i8'),
-                ('covered', '<i8'), ('reserved', '<i8')])
+                ('covered', '<i8'), ('lane_items', '<i8'), ('off_seams', '<i8')])
 SPAN = np.dtype([('dst_y', '<i4'), ('dst_x', '<i4'), ('h', '<i4'), ('w', '<i4'), ('nref', '<i4'), ('ref0', '<i4'),
                  ('pad', '<i4', (2,))])
 REF = np.dtype([('tile', '<i4'), ('src_y', '<i4'), ('src_x', '<i4'), ('pad', '<i4')])
 ITEM = np.dtype([('dst_y', '<i4'), ('dst_x', '<i4'), ('hw', '<i4'), ('nref', '<i4'), ('a', '<i4'), ('b', '<i4'),
                  ('c', '<i4'), ('span', '<i4')])
+SEAM = np.dtype([('a', '<i4'), ('b', '<i4'), ('c', '<i4'), ('flags', '<i4')])
+HAS_LEFT, LEAVE_TAIL, LEFT_ZERO = 1, 2, 4
 
 
 def decode(plan):
@@ -31,6 +33,50 @@ def decode(plan):
     refs = t[hd['off_refs']:hd['off_refs'] + hd['n_refs'] * REF.itemsize].view(REF)
     items = t[hd['off_items']:hd['off_items'] + hd['n_items'] * ITEM.itemsize].view(ITEM)
     return hd, spans, refs, items
+
+
+def decode_seams(plan):
+    t = plan.table
+    hd = t[:HDR.itemsize].view(HDR)[0]
+    assert hd['off_seams'] == hd['off_items'] + hd['n_items'] * ITEM.itemsize
+    return t[hd['off_seams']:hd['off_seams'] + hd['n_items'] * SEAM.itemsize].view(SEAM)
+
+
+def replay_overwrite_with_seams(plan, tiles, pitch, base, flat=None):
+    """What the plane-group kernel writes (fuse.hip process_item_zg): the item right of a seam writes the whole
+    64-pixel line its first pixel falls in, the item left of it stops at that line -- where the line boundaries
+    are follows from the row's address (canvas pitch and base, in pixels)."""
+    hd, spans, refs, items = decode(plan)
+    seams = decode_seams(plan)
+    out = np.full((plan.canvas_h, plan.canvas_w), 0xAAAA, dtype=tiles.dtype)
+    hits = np.zeros((plan.canvas_h, plan.canvas_w), dtype=np.int32)
+
+    def pix(tile, y, x0, x1):
+        v = tiles[tile, y, x0:x1]
+        return O.apply_flatfield(v[None], flat[y:y + 1, x0:x1], tiles.dtype.type)[0] if flat is not None else v
+
+    owned = 0
+    for it, sm in zip(items, seams):
+        h, w = it['hw'] >> 16, it['hw'] & 0xFFFF
+        if sm['flags']:
+            assert w >= 64 and mode_is_overwrite(hd)
+        if sm['flags'] & HAS_LEFT:
+            owned += 1
+        for r in range(h):
+            y, x = it['dst_y'] + r, it['dst_x']
+            mis = (base + y * pitch + x) % 64
+            head = mis if (sm['flags'] & HAS_LEFT) else 0
+            own_end = w - ((w + mis) % 64) if (sm['flags'] & LEAVE_TAIL) else w
+            hits[y, x - head:x + own_end] += 1
+            if head:
+                out[y, x - head:x] = 0 if (sm['flags'] & LEFT_ZERO) else pix(sm['a'], sm['b'] + r, sm['c'] - head, sm['c'])
+            out[y, x:x + own_end] = pix(it['a'], it['b'] + r, it['c'], it['c'] + own_end) if it['nref'] else 0
+    assert (hits == 1).all(), "with seam owners every voxel must still be written exactly once"
+    return out, owned
+
+
+def mode_is_overwrite(hd):
+    return hd['mode'] == native.SQ_FUSE_OVERWRITE
 
 
 def replay_overwrite(plan, tiles, flat=None):
@@ -160,3 +206,44 @@ def test_empty_and_fully_clipped_plans():
     plan = native.FusePlan(np.array([(0, 0, 8, 8, 16, 16), (0, 0, 8, 8, 100, 3)]), 8, 8, 16, 16)
     assert plan.covered_voxels == 0
     np.testing.assert_array_equal(replay_overwrite(plan, np.ones((2, 8, 8), np.uint16)), np.zeros((16, 16), np.uint16))
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_seam_owners_keep_the_partition_at_any_row_phase(seed):
+    """Tiles wide enough for seams (>= 64 columns either side): replaying the table the way the plane-group kernel
+    reads it -- one writer per 128-byte line at a seam -- still writes every voxel once and gives the oracle's
+    canvas, whatever the canvas pitch and base address (they decide where the line boundaries fall in each row)."""
+    rng = np.random.default_rng(100 + seed)
+    th, tw = 40, 200
+    gr, gc = 3, 4
+    rects = []
+    for r in range(gr):
+        for c in range(gc):
+            left = int(rng.integers(0, 30)) if c else 0
+            top = int(rng.integers(0, 8)) if r else 0
+            rects.append((top, left, th - top, tw - left - int(rng.integers(0, 20)),
+                          r * (th - 10) + int(rng.integers(0, 5)) + top, c * (tw - 40) + int(rng.integers(0, 9)) + left))
+    rects = np.array(rects)
+    ch = int((rects[:, 4] + rects[:, 2]).max()) + 7
+    cw = int((rects[:, 5] + rects[:, 3]).max()) + 70 + int(rng.integers(0, 64))     # a zero-fill margin a line wide
+    tiles = rng.integers(0, 65536, size=(len(rects), th, tw), dtype=np.uint16)
+    flat = (0.5 + rng.random((th, tw))).astype(np.float32)
+    plan = native.FusePlan(rects, th, tw, ch, cw)
+    want = O.fuse_plane_overwrite(list(tiles), rects, ch, cw, flat)
+    np.testing.assert_array_equal(replay_overwrite(plan, tiles, flat), want)
+    total = 0
+    for pitch, base in ((cw, 0), (cw + 3, 17), (64 * ((cw + 63) // 64), 0), (cw + 1, 63)):
+        got, owned = replay_overwrite_with_seams(plan, tiles, pitch, base, flat)
+        np.testing.assert_array_equal(got, want)
+        total += owned
+    assert total > 0, "this geometry must produce seams with an owner"
+
+
+def test_wide_span_column_cuts_leave_no_sliver():
+    """A span wider than an item is cut so that no piece is narrower than a line (seams need both sides >= 64)."""
+    plan = native.FusePlan(np.array([(0, 0, 16, 2100, 0, 0)]), 16, 2100, 16, 2100)
+    hd, spans, refs, items = decode(plan)
+    widths = sorted(int(it['hw'] & 0xFFFF) for it in items if it['dst_y'] == 0)
+    assert widths == [116, 1984] and all((it['hw'] >> 16) == 8 for it in items)
+    seams = decode_seams(plan)
+    assert sorted(int(f) for f in seams['flags']) == [HAS_LEFT, HAS_LEFT, LEAVE_TAIL, LEAVE_TAIL]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
     ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
     ap.add_argument('--flags', type=int, default=0)
+    ap.add_argument('--ab', type=int, default=None, help='also time these flags, alternating with --flags in the same process (same buffers)')
     ap.add_argument('--canvas-first', action='store_true', help='allocate the canvas before the tiles')
     ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
@@ -82,6 +83,19 @@ def main():
             print(f'plane {p} mismatched voxels vs oracle:', int(np.count_nonzero(canvas[p].cpu().numpy() != want_p)))
     print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
           f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
+    if a.ab is not None:
+        for rnd in range(4):
+            for fl in (a.flags, a.ab):
+                evs = []
+                for _ in range(a.steps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    native.fuse_planes(plan, tiles, canvas, flats, flags=fl, grid_blocks=a.blocks)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                m = np.array([e0.elapsed_time(e1) for e0, e1 in evs]).mean()
+                print(f'  round {rnd} flags {fl}: {m:.3f} ms ({alg/m/1e6/8000:.4f} of 8 TB/s)', flush=True)
 
 
 if __name__ == '__main__':

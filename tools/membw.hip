@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -259,6 +260,64 @@ __global__ __launch_bounds__(256) void copy_rows(const char *src, char *dst, int
     }
 }
 
+
+// Decomposition of the row-segment pattern: tiles of `rows` row segments of S bytes (S % 16 == 0) at src_pitch,
+// first byte src_off into a tile of src_tile bytes; tile (ty, tx) lands at dst + ty*dst_ty + tx*dst_tx, rows at
+// dst_pitch.  One workgroup per (tile, block of 8 rows), one-shot; wave w copies rows w and w+4 with 16-byte
+// vectors (plain loads, nt stores).  Every address is 16-byte aligned; whether it is 128-byte aligned is the
+// experiment.
+template <int line_slots>
+__global__ __launch_bounds__(256) void copy2d(const char *src, char *dst, int G, int rows, int S, size_t src_tile, size_t src_pitch,
+                                              size_t src_off, size_t dst_pitch, size_t dst_ty, size_t dst_tx, int rpw) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = 4 * rpw, nblk = (rows + per - 1) / per;
+    const size_t it = blockIdx.x;
+    const int tile = (int)(it / nblk), blk = (int)(it % nblk);
+    const int ty = tile / G, tx = tile % G;
+    const int nvec = S / 16;
+    for (int j = 0; j < rpw; ++j) {
+        const int r = blk * per + wave + 4 * j;
+        if (r >= rows) break;
+        const char *s = src + (size_t)tile * src_tile + src_off + (size_t)r * src_pitch;
+        char *d = dst + (size_t)ty * dst_ty + (size_t)tx * dst_tx + (size_t)r * dst_pitch;
+        // line_slots 1: lane 0 of every store instruction sits on a 128-byte line of the DESTINATION (lanes before the
+        // segment masked off), so no instruction straddles a line; 0: lane 0 starts at the segment.
+        // line_slots 2: as 1, and every line has ONE writer: a segment owns the line its first byte falls in (the bytes
+        // before it come from the left neighbour's source row) and leaves the line its end falls in to the right neighbour
+        if (line_slots == 2) {
+            const long x0 = 0, x1 = S;   // relative to d
+            const long a = tx == 0 ? x0 : -(long)((uintptr_t)d & 127);
+            const long b = tx == G - 1 ? x1 : x1 - (long)((uintptr_t)(d + x1) & 127);
+            const char *sl = s - (long)src_tile + S;   // left neighbour's row: its byte S + q pairs with our q < 0
+            const int shift = tx == 0 ? (int)(((uintptr_t)d & 127) >> 4) : 0;
+            u32x4 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const long q = a + ((long)lane + 64 * k - shift) * 16;
+                if (q >= a && q < b) v[k] = ((const G1 U4U *)((q >= 0 ? s : sl) + q))->v;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const long q = a + ((long)lane + 64 * k - shift) * 16;
+                if (q >= a && q < b) __builtin_nontemporal_store(v[k], (G1 u32x4 *)(d + q));
+            }
+            continue;
+        }
+        const int shift = line_slots ? (int)(((uintptr_t)d & 127) >> 4) : 0;
+        u32x4 v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = lane + 64 * k - shift;
+            if (i >= 0 && i < nvec) v[k] = ((const G1 U4U *)(s + (long)i * 16))->v;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = lane + 64 * k - shift;
+            if (i >= 0 && i < nvec) __builtin_nontemporal_store(v[k], (G1 u32x4 *)(d + (long)i * 16));
+        }
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -299,7 +358,67 @@ int main(int argc, char **argv) {
         printf("%-64s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, ms, moved / ms / 1e6, moved / ms / 1e6 / 8000);
         fflush(stdout);
     };
-    char name[160];
+    char name[256];
+
+    if (argc > 2 && !strcmp(argv[2], "2d")) {
+        // one plane = 16 x 16 tiles; each case copies G*G*rows*S bytes
+        const int G = 16, T = 2048;
+        struct Case { const char *what; int rows, S; size_t src_tile, src_pitch, src_off; int dst_kind; int rpw; int line_slots = 0; };
+        // dst_kind 0: canvas (pitch G*S rounded per `pad`), 1: canvas with the unpadded 58276-like pitch (G*S + 560),
+        //          2: packed tile-major (a linear destination), 3: canvas pitch rounded up to 128
+        const Case cases[] = {
+            {"S=4096 rows contiguous -> packed (a linear copy through this kernel)", 2048, 4096, (size_t)T * T * 2, 4096, 0, 2, 2},
+            {"S=4096 whole tiles -> canvas pitch 65536 (all lines whole)", 2048, 4096, (size_t)T * T * 2, 4096, 0, 0, 2},
+            {"S=3584 src off 256 -> canvas pitch 57344 (all lines whole)", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 0, 2},
+            {"S=3584 src off 256 -> packed", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 2, 2},
+            {"S=3584 src packed -> canvas pitch 57344", 1792, 3584, (size_t)1792 * 3584, 3584, 0, 0, 2},
+            {"S=3584 src off 256 -> canvas pitch 57344+560 (rows at every 16-byte phase)", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 1, 2},
+            {"S=3600 src off 240 -> canvas pitch 57600 (tiles at 16-byte phases, rows too)", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 240, 0, 2},
+            {"S=3600 src off 240 -> canvas pitch 57728 (128-multiple; tiles at 16-byte phases)", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 240, 3, 2},
+            {"S=3600 src off 240 -> packed", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 240, 2, 2},
+            {"S=3584 src off 256 -> canvas pitch 57344, 4 rows per wave", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 0, 4},
+            {"S=3584 src off 256 -> canvas pitch 57344, 1 row per wave", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 0, 1},
+            {"S=3584 src off 240 (16-byte phase) -> canvas pitch 57344 (dst lines whole)", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 240, 0, 2},
+            {"S=3584 src off 242 (2-byte phase) -> canvas pitch 57344 (dst lines whole)", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 242, 0, 2},
+            {"S=3584 src off 256 -> canvas pitch 57344+560, LINE SLOTS", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 1, 2, 1},
+            {"S=3600 src off 240 -> canvas pitch 57728, LINE SLOTS", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 240, 3, 2, 1},
+            {"S=3600 src off 242 -> canvas pitch 57600+560, LINE SLOTS", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 242, 1, 2, 1},
+            {"S=3600 src off 242 -> canvas pitch 57600+560", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 242, 1, 2, 0},
+            {"S=3584 src off 256 -> canvas pitch 57344 (all lines whole), LINE SLOTS (control)", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 0, 2, 1},
+            {"S=3584 src off 256 -> canvas pitch 57344+560, ONE WRITER PER LINE", 1792, 3584, (size_t)T * T * 2, 4096, 128 * 4096 + 256, 1, 2, 2},
+            {"S=3600 src off 240 -> canvas pitch 57728, ONE WRITER PER LINE", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 240, 3, 2, 2},
+            {"S=3600 src off 242 -> canvas pitch 57600+560, ONE WRITER PER LINE", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 242, 1, 2, 2},
+            {"S=3600 src off 242 -> canvas pitch 57600+560, ONE WRITER PER LINE, 1 row per wave", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 242, 1, 1, 2},
+            {"S=3600 src off 242 -> canvas pitch 57600+560, LINE SLOTS, 1 row per wave", 1800, 3600, (size_t)T * T * 2, 4096, 124 * 4096 + 242, 1, 1, 1},
+            {"S=2048 half rows -> canvas pitch 32768", 2048, 2048, (size_t)T * T * 2, 4096, 0, 0, 2},
+            {"S=1024 quarter rows -> canvas pitch 16384", 2048, 1024, (size_t)T * T * 2, 4096, 0, 0, 2},
+        };
+        for (const Case &c : cases) {
+            size_t dst_pitch, dst_ty, dst_tx;
+            if (c.dst_kind == 2) { dst_pitch = c.S; dst_tx = (size_t)c.rows * c.S; dst_ty = (size_t)G * dst_tx; }
+            else {
+                dst_pitch = (size_t)G * c.S + (c.dst_kind == 1 ? 560 : 0);
+                if (c.dst_kind == 3) dst_pitch = (dst_pitch + 127) / 128 * 128;
+                dst_tx = c.S; dst_ty = (size_t)c.rows * dst_pitch;
+            }
+            const size_t plane_src = (size_t)G * G * c.src_tile, plane_dst = ((size_t)G * c.rows * (c.dst_kind == 2 ? (size_t)G * c.S : dst_pitch) + 4095) / 4096 * 4096;
+            const int nplanes = (int)std::min(bytes / plane_src, bytes / plane_dst);
+            const int per = 4 * c.rpw;
+            const size_t n_items = (size_t)G * G * ((c.rows + per - 1) / per);
+            double ms = time_ms([&] {
+                for (int p = 0; p < nplanes; ++p)
+                {
+                    auto k = c.line_slots == 2 ? copy2d<2> : (c.line_slots == 1 ? copy2d<1> : copy2d<0>);
+                    hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), 0, 0, src + p * plane_src, dst + p * plane_dst, G, c.rows, c.S,
+                                       c.src_tile, c.src_pitch, c.src_off, dst_pitch, dst_ty, dst_tx, c.rpw);
+                }
+            });
+            snprintf(name, sizeof name, "2d %s, %d planes", c.what, nplanes);
+            printf("%-100s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, ms, 2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6, 2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6 / 8000);
+            fflush(stdout);
+        }
+        return 0;
+    }
 #define COPY(U, NTL, NTS, PER_CU)                                                                                   \
     do {                                                                                                            \
         const size_t nch = nvec / (256 * U);                                                                        \
