@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ab', type=int, default=None, help='also time these flags, alternating with --flags in the same process (same buffers)')
+    ap.add_argument('--libs', default=None, help='comma-separated build variants (tools/build_variant.sh names, or "default") timed alternately in this process on the same buffers')
     ap.add_argument('--canvas-first', action='store_true', help='allocate the canvas before the tiles')
     ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
@@ -83,6 +84,36 @@ def main():
             print(f'plane {p} mismatched voxels vs oracle:', int(np.count_nonzero(canvas[p].cpu().numpy() != want_p)))
     print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
           f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
+    if a.libs:
+        import ctypes as C
+        here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'image-stitcher_amd', 'csrc')
+        handles, plans = {}, {}
+        for name in a.libs.split(','):
+            h = C.CDLL(os.path.join(here, 'libsquidstitch.so' if name == 'default' else f'libsquidstitch_{name}.so'))
+            for fn, (res, args) in native.EXPORTS.items():
+                getattr(h, fn).restype = res
+                getattr(h, fn).argtypes = args
+            handles[name] = h
+            native._lib = h
+            plans[name] = native.FusePlan(rects, T, T, hc, wc)
+        for rnd in range(4):
+            for name in handles:
+                native._lib = handles[name]
+                for _ in range(1 if rnd else 2):
+                    native.fuse_planes(plans[name], tiles, canvas, flats, flags=a.flags, grid_blocks=a.blocks)
+                evs = []
+                for _ in range(a.steps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    native.fuse_planes(plans[name], tiles, canvas, flats, flags=a.flags, grid_blocks=a.blocks)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                m = np.array([e0.elapsed_time(e1) for e0, e1 in evs]).mean()
+                bad = ''
+                if a.check and rnd == 0:
+                    bad = f', plane 0 mismatched voxels: {int(np.count_nonzero(canvas[0].cpu().numpy() != want))}'
+                print(f'  round {rnd} {name}: {m:.3f} ms ({alg/m/1e6/8000:.4f} of 8 TB/s), {plans[name].n_items} items{bad}', flush=True)
     if a.ab is not None:
         for rnd in range(4):
             for fl in (a.flags, a.ab):

@@ -318,6 +318,39 @@ __global__ __launch_bounds__(256) void copy2d(const char *src, char *dst, int G,
     }
 }
 
+// the same tiles, the other way round: the four waves of a workgroup share ONE row at a time (wave w copies the w-th
+// KiB of the segment, one vector per lane) and walk down the block's rows together -- a workgroup then touches 4 KiB
+// of one row at once instead of 1 KiB of four rows
+template <int ROWS_PER_WG, int Z>
+__global__ __launch_bounds__(256) void copy2d_rowwise(const char *src, char *dst, int G, int rows, int S, size_t src_tile, size_t src_pitch,
+                                                      size_t src_off, size_t dst_pitch, size_t dst_ty, size_t dst_tx, size_t src_z, size_t dst_z) {
+    const int nblk = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const size_t it = blockIdx.x;
+    const int tile = (int)(it / nblk), blk = (int)(it % nblk);
+    const int ty = tile / G, tx = tile % G;
+    const int nvec = S / 16;
+    u32x4 v[ROWS_PER_WG][Z];
+    const int r0 = blk * ROWS_PER_WG;
+    const char *s = src + (size_t)tile * src_tile + src_off + (size_t)r0 * src_pitch;
+    char *d = dst + (size_t)ty * dst_ty + (size_t)tx * dst_tx + (size_t)r0 * dst_pitch;
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_WG; ++j) {
+        const int shift = (int)(((uintptr_t)(d + j * dst_pitch) & 127) >> 4);
+        const int i = (int)threadIdx.x - shift;
+        if (r0 + j < rows && i >= 0 && i < nvec)
+#pragma unroll
+            for (int z = 0; z < Z; ++z) v[j][z] = ((const G1 U4U *)(s + z * src_z + j * src_pitch + (long)i * 16))->v;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_WG; ++j) {
+        const int shift = (int)(((uintptr_t)(d + j * dst_pitch) & 127) >> 4);
+        const int i = (int)threadIdx.x - shift;
+        if (r0 + j < rows && i >= 0 && i < nvec)
+#pragma unroll
+            for (int z = 0; z < Z; ++z) __builtin_nontemporal_store(v[j][z], (G1 u32x4 *)(d + z * dst_z + j * dst_pitch + (long)i * 16));
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -416,6 +449,41 @@ int main(int argc, char **argv) {
             snprintf(name, sizeof name, "2d %s, %d planes", c.what, nplanes);
             printf("%-100s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, ms, 2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6, 2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6 / 8000);
             fflush(stdout);
+        }
+
+        // row-wise workgroups (S <= 4096 - 128: 256 lanes cover the segment at any phase)
+        {
+            struct RC { const char *what; int rows, S; size_t src_off; int dst_kind; };
+            const RC rcs[] = {
+                {"S=3584 src off 256 -> canvas pitch 57344 (all lines whole)", 1792, 3584, 128 * 4096 + 256, 0},
+                {"S=3584 src off 256 -> canvas pitch 57344+560 (line slots)", 1792, 3584, 128 * 4096 + 256, 1},
+                {"S=3600 src off 242 -> canvas pitch 57600+560 (line slots)", 1800, 3600, 124 * 4096 + 242, 1},
+            };
+            for (const RC &c : rcs) {
+                const size_t src_tile = (size_t)T * T * 2;
+                size_t dst_pitch = (size_t)G * c.S + (c.dst_kind == 1 ? 560 : 0), dst_tx = c.S, dst_ty = (size_t)c.rows * dst_pitch;
+                const size_t plane_src = (size_t)G * G * src_tile, plane_dst = ((size_t)G * c.rows * dst_pitch + 4095) / 4096 * 4096;
+                const int nplanes = (int)std::min(bytes / plane_src, bytes / plane_dst);
+#define RW(N, Z)                                                                                                                 \
+    do {                                                                                                                         \
+        const size_t n_items = (size_t)G * G * ((c.rows + N - 1) / N);                                                           \
+        double ms = time_ms([&] {                                                                                                \
+            for (int p = 0; p + Z <= nplanes; p += Z)                                                                            \
+                hipLaunchKernelGGL((copy2d_rowwise<N, Z>), dim3((unsigned)n_items), dim3(256), 0, 0, src + p * plane_src, dst + p * plane_dst, G, \
+                                   c.rows, c.S, src_tile, (size_t)4096, c.src_off, dst_pitch, dst_ty, dst_tx, plane_src, plane_dst); \
+        });                                                                                                                      \
+        snprintf(name, sizeof name, "2d ROW-WISE WG, %d rows per workgroup, %d planes per thread: %s, %d planes", N, Z, c.what, nplanes / Z * Z); \
+        printf("%-125s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, ms, 2.0 * G * G * c.rows * c.S * (nplanes / Z * Z) / ms / 1e6, \
+               2.0 * G * G * c.rows * c.S * (nplanes / Z * Z) / ms / 1e6 / 8000);                                                \
+        fflush(stdout);                                                                                                          \
+    } while (0)
+                RW(1, 1);
+                RW(2, 1);
+                RW(4, 1);
+                RW(1, 2);
+                RW(1, 4);
+                RW(2, 4);
+            }
         }
         return 0;
     }
