@@ -351,6 +351,39 @@ __global__ __launch_bounds__(256) void copy2d_rowwise(const char *src, char *dst
     }
 }
 
+// the row-wise workgroup again, R rows per workgroup one after the other, but with at most DEPTH loads of a thread in
+// flight: load row j + DEPTH, then wait for row j (vmcnt in issue order) and store it
+template <int R, int DEPTH>
+__global__ __launch_bounds__(256) void copy2d_rowwise_depth(const char *src, char *dst, int G, int rows, int S, size_t src_tile, size_t src_pitch,
+                                                            size_t src_off, size_t dst_pitch, size_t dst_ty, size_t dst_tx) {
+    const int nblk = (rows + R - 1) / R;
+    const size_t it = blockIdx.x;
+    const int tile = (int)(it / nblk), blk = (int)(it % nblk);
+    const int ty = tile / G, tx = tile % G;
+    const int nvec = S / 16;
+    const int r0 = blk * R;
+    const char *s = src + (size_t)tile * src_tile + src_off + (size_t)r0 * src_pitch;
+    char *d = dst + (size_t)ty * dst_ty + (size_t)tx * dst_tx + (size_t)r0 * dst_pitch;
+    u32x4 v[DEPTH];
+    auto ld = [&](int j) {
+        const int shift = (int)(((uintptr_t)(d + j * dst_pitch) & 127) >> 4);
+        const int i = min(max((int)threadIdx.x - shift, 0), nvec - 1);
+        return ((const G1 U4U *)(s + j * src_pitch + (long)i * 16))->v;
+    };
+#pragma unroll
+    for (int j = 0; j < DEPTH && j < R; ++j) v[j] = ld(min(j, rows - 1 - r0));
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        u32x4 cur = v[j % DEPTH];
+        // wait until only the younger DEPTH - 1 loads are outstanding (stores count too: they are older or this row's)
+        if (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur));
+        const int shift = (int)(((uintptr_t)(d + j * dst_pitch) & 127) >> 4);
+        const int i = (int)threadIdx.x - shift;
+        if (r0 + j < rows && i >= 0 && i < nvec) __builtin_nontemporal_store(cur, (G1 u32x4 *)(d + j * dst_pitch + (long)i * 16));
+        if (j + DEPTH < R) v[j % DEPTH] = ld(min(j + DEPTH, rows - 1 - r0));
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -477,6 +510,27 @@ int main(int argc, char **argv) {
                2.0 * G * G * c.rows * c.S * (nplanes / Z * Z) / ms / 1e6 / 8000);                                                \
         fflush(stdout);                                                                                                          \
     } while (0)
+#define RD(N, D)                                                                                                                 \
+    do {                                                                                                                         \
+        const size_t n_items = (size_t)G * G * ((c.rows + N - 1) / N);                                                           \
+        double ms = time_ms([&] {                                                                                                \
+            for (int p = 0; p < nplanes; ++p)                                                                                    \
+                hipLaunchKernelGGL((copy2d_rowwise_depth<N, D>), dim3((unsigned)n_items), dim3(256), 0, 0, src + p * plane_src, dst + p * plane_dst, G, \
+                                   c.rows, c.S, src_tile, (size_t)4096, c.src_off, dst_pitch, dst_ty, dst_tx);                  \
+        });                                                                                                                      \
+        snprintf(name, sizeof name, "2d ROW-WISE WG, %d rows one after the other, <= %d loads in flight per thread: %s, %d planes", N, D, c.what, nplanes); \
+        printf("%-125s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, ms, 2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6,    \
+               2.0 * G * G * c.rows * c.S * nplanes / ms / 1e6 / 8000);                                                          \
+        fflush(stdout);                                                                                                          \
+    } while (0)
+                RD(4, 1);
+                RD(4, 2);
+                RD(8, 1);
+                RD(8, 2);
+                RD(16, 2);
+                RD(16, 4);
+                RD(64, 2);
+                RD(64, 4);
                 RW(1, 1);
                 RW(2, 1);
                 RW(4, 1);
