@@ -53,6 +53,7 @@ WORKLOADS = {
 }
 TILE, OVERLAP, DRIFT = 2048, 244, (3, -2)
 HBM_PEAK_GBS = 8000.0
+GROUP = 5            # planes the fusion kernel carries through an item together (ZB in csrc/fuse.hip)
 # the genuine reference (unmodified /root/reference/stitcher.py, scikit-image 0.18.3, dask's threaded scheduler)
 # cannot travel to the GPU box; its timing is from the authoring container (tools/time_reference.py)
 REFERENCE_TIMING = {'value': 18.6, 'unit': 'Mvoxel/s', 'cores': 8, 'kind': 'reference',
@@ -68,7 +69,7 @@ def main():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default=None,
                     help='default: cfg3 on one GPU, cfg4 (the headline job, strong scaling) on several')
     ap.add_argument('--planes', type=int, default=0, help='override the number of (c,z) planes (resident planes / job size)')
-    ap.add_argument('--batch', type=int, default=0, help='cfg4: planes per resident batch (default: what fits, at most 12)')
+    ap.add_argument('--batch', type=int, default=0, help='cfg4: planes per resident batch (default: what fits, at most 10, a multiple of 5)')
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
@@ -441,16 +442,16 @@ def run_job(ctx):
     g, C, Z = wl['grid'], wl['channels'], wl['nz']
     total_planes = args.planes or C * Z
     spec, truth, wc, hc, xs, ys, order, order_rc = grid_setup(g, 1000 * 4)     # every rank: the SAME acquisition
-    mine = sharding.block_cyclic(total_planes, rank, world)                    # plane p = c * Z + z  ->  rank p % world
+    # plane p = c * Z + z; every rank ONE contiguous run of planes (the z planes of a channel share a gain image: kept
+    # together they go through the kernel in groups of 5, csrc/fuse.hip), cut into resident batches of a multiple of 5
+    mine = sharding.contiguous_blocks(total_planes, rank, world)
     plane_in, plane_out = g * g * TILE * TILE * 2, hc * wc * 2
     free, _ = torch.cuda.mem_get_info(dev)
     fit = int((free - (8 << 30)) // (plane_in + plane_out))
     if fit < 1:
         raise SystemExit(f"[bench] not even one plane of the 32x32 grid fits in {free / 2**30:.0f} GiB of free HBM")
-    cap = args.batch or min(fit, 12)
-    n_batches = max(1, -(-len(mine) // cap))
-    bsz = -(-len(mine) // n_batches) if mine else 0          # balanced batches: 25 planes -> 9, 8, 8
-    batches = [mine[i:i + bsz] for i in range(0, len(mine), bsz)] if bsz else []
+    cap = args.batch or max(1, min(fit, 2 * GROUP) // GROUP * GROUP or min(fit, GROUP - 1))
+    batches = [mine[i:i + cap] for i in range(0, len(mine), cap)]
     bmax = max((len(b) for b in batches), default=1)
 
     tiles = torch.empty((bmax, g * g, TILE, TILE), dtype=torch.uint16, device=dev)
@@ -572,7 +573,7 @@ def run_job(ctx):
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'config': {'workload': wl['desc'], 'planes_total': total_planes, 'planes_per_gpu': len(mine),
                    'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g,
-                   'parallelism': f'planes block-cyclic over {world} GPUs (plane p -> rank p % {world}), rank 0 registers, '
+                   'parallelism': f'planes dealt over {world} GPUs in contiguous runs (a channel\'s z planes stay together), rank 0 registers, '
                                   f'shift row all-gathered over {"RCCL" if ctx["backend"] == "nccl" else ctx["backend"]}, no image data exchanged',
                    'shifts': {'h': list(shifts.h_shift), 'v': list(shifts.v_shift)},
                    'step': 'the whole job: centre-pair PCC on rank 0 + all-gather + span plan (kept while the shifts stay), then per '

@@ -57,6 +57,18 @@ def block_cyclic(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+def contiguous_blocks(n_items: int, rank: int, world: int) -> List[int]:
+    """Indices of the work items rank ``rank`` owns when every rank takes ONE contiguous run (sizes differ by at most
+    one, the longer runs first).  Used for the (channel, z) planes of a region: consecutive planes are the z planes of
+    one channel, which share a gain image -- kept on one rank they go through the fusion kernel together (plane groups,
+    csrc/fuse.hip) and their files sit side by side."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
 def row_bands(canvas_h: int, num_levels: int, chunk_rows: int = 512) -> List[Tuple[int, int]]:
     """Level-0 row bands [y0, y1) that ONE (channel, z) plane can be cut into so that several ranks fuse and write it
     at once (the finest grain; precedent: the reference's per-FOV writers into one pre-created array,
@@ -70,9 +82,10 @@ def row_bands(canvas_h: int, num_levels: int, chunk_rows: int = 512) -> List[Tup
 
 def plane_band_units(n_planes: int, bands: Sequence[Tuple[int, int]], rank: int, world: int) -> List[Tuple[int, int]]:
     """(plane, band index) work units of rank ``rank``: planes first when there are enough of them (whole planes,
-    no tile is read twice), else every plane cut into its bands -- dealt block-cyclically either way."""
+    no tile is read twice; every rank a contiguous run of planes), else every plane cut into its bands, dealt
+    block-cyclically."""
     if n_planes >= world or len(bands) <= 1:
-        return [(p, -1) for p in block_cyclic(n_planes, rank, world)]      # -1: the whole plane
+        return [(p, -1) for p in contiguous_blocks(n_planes, rank, world)]      # -1: the whole plane
     units = [(p, b) for p in range(n_planes) for b in range(len(bands))]
     return [units[i] for i in block_cyclic(len(units), rank, world)]
 

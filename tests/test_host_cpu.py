@@ -300,7 +300,7 @@ def test_row_bands_and_plane_band_units():
             for lv in range(levels):      # a band starts on a chunk row of every level
                 assert (y0 >> lv) % min(512, max(1, h >> lv)) == 0
     # enough planes: whole planes; fewer planes than ranks: (plane, band) units, each exactly once
-    assert sharding.plane_band_units(4, [(0, 10), (10, 20)], 1, 2) == [(1, -1), (3, -1)]
+    assert sharding.plane_band_units(4, [(0, 10), (10, 20)], 1, 2) == [(2, -1), (3, -1)]
     seen = sorted(u for r in range(3) for u in sharding.plane_band_units(1, [(0, 1), (1, 2), (2, 3), (3, 4)], r, 3))
     assert seen == [(0, b) for b in range(4)]
     assert sharding.plane_band_units(1, [(0, 9)], 0, 4) == [(0, -1)] and sharding.plane_band_units(1, [(0, 9)], 1, 4) == []

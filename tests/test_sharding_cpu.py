@@ -21,6 +21,9 @@ def test_block_cyclic_covers_everything_once():
         for world in (1, 2, 3, 8):
             seen = sorted(i for r in range(world) for i in sharding.block_cyclic(n, r, world))
             assert seen == list(range(n))
+            blocks = [sharding.contiguous_blocks(n, r, world) for r in range(world)]
+            assert [i for b in blocks for i in b] == list(range(n))                      # runs, in rank order
+            assert max(map(len, blocks)) - min(map(len, blocks)) <= 1
             sizes = [len(sharding.block_cyclic(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
