@@ -203,19 +203,6 @@ __device__ __forceinline__ T flat_f32_fast(T v, float g) {
     const uint32_t k = cvt_u32_sat(quotient_u16_normal<RND>((float)v, g));
     return (T)min(k, sizeof(T) == 1 ? 255u : 65535u);
 }
-#ifndef SQ_RCP_TABLE
-#define SQ_RCP_TABLE 0   // experiment: 1 = a plane of correctly rounded reciprocals follows the gains in memory
-#endif
-// the same with the reciprocal read from a table (correctly rounded: error <= 1/2 ulp, better than v_rcp_f32's 1 ulp)
-__device__ __forceinline__ uint32_t flat_f32_table_pair(uint32_t word, float g_lo, float g_hi, float r_lo, float r_hi) {
-    const float n0 = (float)(word & 0xFFFFu), n1 = (float)(word >> 16);
-    const float q0 = n0 * r_lo, q1 = n1 * r_hi;
-    const uint32_t a = cvt_u32_sat(fmaf(fmaf(-g_lo, q0, n0), r_lo, q0));
-    const uint32_t b = cvt_u32_sat(fmaf(fmaf(-g_hi, q1, n1), r_hi, q1));
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
-}
 // two pixels of one 32-bit word at once: v_cvt_pk_u16_u32 saturates to 65535 and packs
 template <int RND = 0>
 __device__ __forceinline__ uint32_t flat_f32_fast_pair(uint32_t word, float g_lo, float g_hi) {
@@ -302,9 +289,6 @@ struct Row {
     T *drow;
     const T *srow;
     const char *frow;
-#if SQ_RCP_TABLE
-    int64_t rofs;   // bytes from a gain to its reciprocal
-#endif
     int mis, n;
     int v_first, v_end;   // whole vectors are v in [v_first, v_end)
     int edge_p;           // this lane's edge pixel (or -1)
@@ -315,9 +299,6 @@ struct Slot {
     static constexpr int VEC = Pix<T>::N;
     u32x4 px;
     f32x4 g32[FLAT == 1 ? VEC / 4 : 1];
-#if SQ_RCP_TABLE
-    f32x4 r32[FLAT == 1 ? VEC / 4 : 1];
-#endif
     f64x2 g64[FLAT == 2 ? VEC / 2 : 1];
     T edge;
     float eg32;
@@ -357,10 +338,6 @@ __device__ __forceinline__ void slot_load(Slot<T, FLAT> &S, const Row<T> &J, int
         if (FLAT == 1 && J.frow) {
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) S.g32[q] = ldg<F32x4U>(reinterpret_cast<const float *>(J.frow) + p0 + 4 * q);
-#if SQ_RCP_TABLE
-#pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) S.r32[q] = ldg<F32x4U>(reinterpret_cast<const float *>(J.frow + J.rofs) + p0 + 4 * q);
-#endif
         }
         if (FLAT == 2 && J.frow) {
 #pragma unroll
@@ -385,13 +362,6 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
             if (FAST && sizeof(T) == 2) {   // every gain of this plane is inside the fast range (pre-pass flag)
 #pragma unroll
                 for (int q = 0; q < VEC / 4; ++q) {
-#if SQ_RCP_TABLE
-                    if (!RND) {
-                        px[2 * q] = flat_f32_table_pair(px[2 * q], S.g32[q][0], S.g32[q][1], S.r32[q][0], S.r32[q][1]);
-                        px[2 * q + 1] = flat_f32_table_pair(px[2 * q + 1], S.g32[q][2], S.g32[q][3], S.r32[q][2], S.r32[q][3]);
-                        continue;
-                    }
-#endif
                     px[2 * q] = flat_f32_fast_pair<RND>(px[2 * q], S.g32[q][0], S.g32[q][1]);
                     px[2 * q + 1] = flat_f32_fast_pair<RND>(px[2 * q + 1], S.g32[q][2], S.g32[q][3]);
                 }
@@ -514,9 +484,6 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
             J[j].drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
             J[j].srow = tile + (int64_t)(it.b + r) * P.tile_pitch + it.c;
             J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
-#if SQ_RCP_TABLE
-            J[j].rofs = (int64_t)P.tile_h * P.tile_w * 4;
-#endif
             row_setup<T>(J[j], lane);
         }
         if (fast) pipeline_rows<T, FLAT, true, RND, RB, SLOTS, DEPTH>(J, lane);
@@ -892,9 +859,6 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
     };
     auto body = [&](int, const Item &it, const UnitAux &A) {
         const int gn = sgpr(A.g.n);
-#ifdef SQ_ZG_FULL_ONLY     /* experiment: full groups only (plane counts that are multiples of ZB) */
-        if (gn == ZB) process_item_zg<true>(P, A, gn, it, wave, lane);
-#else
         if (gn == 1) {
             process_item<T, 1>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
         } else if (gn == ZB) {
@@ -902,7 +866,6 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
         } else {
             process_item_zg<false>(P, A, gn, it, wave, lane);
         }
-#endif
     };
     if (DYN) {
         for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);

@@ -21,7 +21,6 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--nflats', type=int, default=1, help='distinct flatfields, dealt to planes in blocks (channels)')
     ap.add_argument('--drift', type=int, nargs=2, default=[3, -2])
-    ap.add_argument('--rcp', action='store_true', help='gains as [2, H, W]: gains, then correctly rounded reciprocals (-DSQ_RCP_TABLE=1 builds)')
     ap.add_argument('--check', action='store_true', help='compare plane 0 with the oracle')
     ap.add_argument('--dense', action='store_true', help='dense canvas stack (plane stride = Hc*Wc): no plane groups')
     ap.add_argument('--flags', type=int, default=0)
@@ -57,10 +56,7 @@ def main():
     flats = None
     if a.flat != 'none':
         g = synth.synthetic_flatfield(T, T, np.float32 if a.flat == 'f32' else np.float64)
-        if a.rcp:
-            ffs = [torch.from_numpy(np.stack([g, (g.dtype.type(1) / g).astype(g.dtype)])).to(dev)[0] for _ in range(a.nflats)]
-        else:
-            ffs = [torch.from_numpy(g).to(dev) for _ in range(a.nflats)]
+        ffs = [torch.from_numpy(g).to(dev) for _ in range(a.nflats)]
         flats = [ffs[p * a.nflats // a.planes] for p in range(a.planes)]
     for _ in range(2):
         native.fuse_planes(plan, tiles, canvas, flats, flags=a.flags, grid_blocks=a.blocks)
