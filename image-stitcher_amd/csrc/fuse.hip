@@ -92,7 +92,8 @@ struct FuseParams {
     int64_t canvas_plane_stride;
     int32_t n_tiles, tile_h, tile_w, tile_pitch;
     int32_t canvas_pitch;
-    const uint32_t *flat_class;   // per plane: 0 = every gain is a normal float (fast divide allowed)
+    const uint32_t *flat_class;   // per plane: bit 0 clear = every gain is a normal float in the fast divide's range; bit 1 clear =
+                                  // every gain is also moderate (2^-20 <= |g| < 2^20: what the grouped feather blend asks for)
     uint32_t *queue;              // 9 chunk counters (8 XCD lanes + the rest), one 128-byte line each; NULL = static stride
     int32_t lane_items;           // list positions [0, 8 * lane_items) of a plane are lane-interleaved
     int32_t n_planes;
@@ -170,6 +171,8 @@ __device__ __forceinline__ float div_u16_normal(float n, float g) {
 }
 constexpr int FAST_MIN_EXP = -100;   // fast divide allowed for 2^FAST_MIN_EXP <= |g| < 2^FAST_END_EXP:
 constexpr int FAST_END_EXP = 100;    // (every non-zero quotient n/g is then a normal float)
+constexpr int BLEND_ACC_MIN_EXP = -44, BLEND_ACC_END_EXP = 53, BLEND_WSUM_MAX = 16384;   // what the grouped blend's last division sees
+constexpr int MODERATE_EXP = 20;     // grouped feather blend: 2^-20 <= |g| < 2^20 keeps sums of weighted quotients far from the range ends
 
 // float -> uint32 the way the hardware does it: negative and NaN -> 0, too large -> 0xFFFFFFFF.
 // (C++'s (uint32_t)f is undefined outside the range, so say the instruction.)
@@ -474,7 +477,7 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
         return;
     }
     const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
-    const bool fast = FLAT != 0 && P.flat_class && P.flat_class[plane] == 0;
+    const bool fast = FLAT != 0 && P.flat_class && (P.flat_class[plane] & 1u) == 0;
     for (int rb = wave; rb < rows; rb += 4 * RB) {
         Row<T> J[RB];
 #pragma unroll
@@ -650,8 +653,9 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
 struct UnitAux {
     PlaneGroup g;
     const void *tile[ZB];
-    const void *ltile[ZB];  // the planes' tiles left of the seam this item owns (Seam in common.h)
-    Seam seam;
+    const void *ltile[ZB];  // the planes' tiles left of the seam this item owns (Seam in common.h); feather: the second reference's
+    Seam seam;              // feather: tile and source origin of a blended item's second reference (flags 0)
+    Seam first;             // feather: tile and source origin of the item's first reference
 };
 
 // RND = 0 (overwrite: truncate): Markstein with r = v_rcp_f32(g), the arithmetic of div_u16_normal.
@@ -889,9 +893,10 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
 // One block: deal the planes into groups of <= zb that share a gain image (and a fast gain class, and the phase
 // of their canvas inside a 128-byte line).  Planes are few (C x Z of a region); more than CAP of them, or zb = 1,
 // and every plane is its own group.
-__global__ __launch_bounds__(256) void build_groups_kernel(const void *const *flat_ptrs, const uint32_t *cls, int n_planes,
-                                                          int64_t plane_stride_bytes, int zb, uint32_t *n_groups,
+__global__ __launch_bounds__(256) void build_groups_kernel(const void *const *flat_ptrs, const uint32_t *cls, uint32_t cls_mask,
+                                                          int n_planes, int64_t plane_stride_bytes, int zb, uint32_t *n_groups,
                                                           PlaneGroup *groups) {
+    // flat_ptrs == NULL (feather without gains): the planes share their geometry only, any of them may go together
     constexpr int CAP = 1024;
     __shared__ uint64_t key[CAP];
     __shared__ int first[CAP], open_group[CAP];
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(256) void build_groups_kernel(const void *const *fl
     }
     for (int p = tid; p < n_planes; p += 256) {
         const void *f = flat_ptrs ? flat_ptrs[p] : nullptr;
-        const bool ok = f && cls[p] == 0;
+        const bool ok = flat_ptrs ? (f && (cls[p] & cls_mask) == 0) : true;
         // 0 = "groups with nobody"; else the gain pointer (< 2^56) and the canvas plane's phase in a line
         key[p] = ok ? ((reinterpret_cast<uint64_t>(f) << 7) | (uint64_t)(((int64_t)p * plane_stride_bytes) & 127) | (1ull << 63)) : 0;
         open_group[p] = -1;
@@ -1132,6 +1137,33 @@ __device__ __forceinline__ void blend_item(const FuseParams &P, int plane, const
     }
 }
 
+// one (plane, item) of a feather plan, all threads of the workgroup together
+template <typename T, typename OutT, int FLAT>
+__device__ __forceinline__ void feather_one_item(const FuseParams &P, int plane, const Item &it, int wave, int lane) {
+    const int nref = it.nref;
+    if (sizeof(OutT) == sizeof(T) && FLAT != 2 && nref <= 1) {
+        // nothing to blend: uncovered canvas, or one tile -> the overwrite kernel's pipelined copy
+        // (with float32 gains: divide, round half to even, clip -- what the blend yields for a
+        // single reference)
+        Item one = it;
+        const T *tile = nullptr;
+        if (nref) {
+            const Ref rf = P.refs[it.a];
+            tile = tile_ptr<T>(P, plane, rf.tile);
+            one.a = rf.tile;
+            one.b = rf.src_y + it.b;
+            one.c = rf.src_x + it.c;
+        }
+        process_item<T, FLAT == 2 ? 0 : FLAT, 1>(P, plane, one, tile, wave, lane);
+        return;
+    }
+    // float32 gains the pre-pass found all normal: the 8-slot divide, bit-identical to the IEEE
+    // quotient for this operand class (exhaustive self-test), instead of the 11-slot generic one
+    const bool fast = FLAT == 1 && P.flat_class && (P.flat_class[plane] & 1u) == 0;
+    if (fast) blend_item<T, OutT, FLAT, true>(P, plane, it, threadIdx.x);
+    else blend_item<T, OutT, FLAT, false>(P, plane, it, threadIdx.x);
+}
+
 #ifndef SQ_WAVES_FEATHER_F32
 #define SQ_WAVES_FEATHER_F32 5
 #endif
@@ -1140,46 +1172,230 @@ __global__ __launch_bounds__(256, (FLAT == 1 && sizeof(T) == 2 && sizeof(OutT) =
 void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    auto one_item = [&](int plane, const Item &it) {
-        const int nref = it.nref;
-        if (sizeof(OutT) == sizeof(T) && FLAT != 2 && nref <= 1) {
-            // nothing to blend: uncovered canvas, or one tile -> the overwrite kernel's pipelined copy
-            // (with float32 gains: divide, round half to even, clip -- what the blend yields for a
-            // single reference)
-            Item one = it;
-            const T *tile = nullptr;
-            if (nref) {
-                const Ref rf = P.refs[it.a];
-                tile = tile_ptr<T>(P, plane, rf.tile);
-                one.a = rf.tile;
-                one.b = rf.src_y + it.b;
-                one.c = rf.src_x + it.c;
-            }
-            process_item<T, FLAT == 2 ? 0 : FLAT, 1>(P, plane, one, tile, wave, lane);
-            return;
-        }
-        // float32 gains the pre-pass found all normal: the 8-slot divide, bit-identical to the IEEE
-        // quotient for this operand class (exhaustive self-test), instead of the 11-slot generic one
-        const bool fast = FLAT == 1 && P.flat_class && P.flat_class[plane] == 0;
-        if (fast) blend_item<T, OutT, FLAT, true>(P, plane, it, threadIdx.x);
-        else blend_item<T, OutT, FLAT, false>(P, plane, it, threadIdx.x);
-    };
     if (DYN) {
         // single-tile and blended items cost very differently: the queues (one "rest" queue here, the
         // feather plan is not lane-interleaved) keep every workgroup busy until the end
         for_each_queued_item<int>(P, n_items, (uint32_t)P.n_planes, [](int, const Item &, int64_t) -> int { return 0; },
-                                  [&](int plane, const Item &it, const int &) { one_item(plane, it); });
+                                  [&](int plane, const Item &it, const int &) { feather_one_item<T, OutT, FLAT>(P, plane, it, wave, lane); });
     } else {
         for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
             const int plane = (int)(work / n_items);
-            one_item(plane, P.items[work - plane * n_items]);
+            feather_one_item<T, OutT, FLAT>(P, plane, P.items[work - plane * n_items], wave, lane);
         }
     }
 }
 
-// (Plane groups for feather mode's one-tile items with gains -- process_item_zg<.., RND = 1> -- were built and measured in
-// round 2: 0.377-0.389 against 0.368 without them at equal item height, and slower than without at 32-row blend items
-// (profiles/r02_exp9_feather.log): the blended strips, two divides per output pixel, set that mode's time.  Not kept.)
+// ---------------------------------------------------------------------------------------------
+// feather mode, uint16 tiles and canvas, float32 gains: plane groups
+// ---------------------------------------------------------------------------------------------
+// The z planes of a channel share the gain image AND the geometry, so everything of a blended voxel that does not
+// depend on the pixel values is the same for them: the two gains and their refined reciprocals, the two weights, their
+// sum and ITS refined reciprocal.  A thread works that out once per 8-pixel group and then runs the planes' pixels
+// through it: per plane and voxel two quotients of 5 instructions (div_u16_normal_ieee with the reciprocal handed in),
+// two products, one sum, the division by the weight sum in the same 5-instruction form, round, clip, pack -- about 27
+// VALU instructions against 45 for a plane on its own.  The arithmetic is the per-plane blend's, operation for
+// operation: v_k = n_k / g_k correctly rounded, acc = w_0 v_0 + w_1 v_1 (multiply and add separate), acc / wsum
+// correctly rounded.  The last one is the IEEE sequence (Newton step on the reciprocal, quotient, two exact-residual
+// corrections) without its v_div_scale / v_div_fmas / v_div_fixup range handling, which cannot trigger here: wsum is an
+// integer in [2, 2^14], and with every gain of the plane moderate (2^-20 <= |g| < 2^20: bit 1 of the gain class, else
+// the plane is a group of one) acc is 0 or 2^-44 <= |acc| < 2^53.  sq_selftest_blend_divide compares it with the
+// compiler's division on the device.
+// Items of one tile go through process_item_zg<.., RND = 1>; spans that three or four tiles cover (the corners of a
+// grid, (overlap / tile)^2 of the canvas) take the per-plane blend, plane after plane.
+__device__ __forceinline__ float div_by_refined(float n, float d, float r) {   // r = recip_for<1>(d)
+    float q = n * r;
+    q = fmaf(fmaf(-d, q, n), r, q);
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+
+template <int FLAT, bool FULL>
+__device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it, const int tid) {
+    typedef uint16_t T;
+    constexpr int VEC = 8;
+    const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    T *cplane[ZB];
+    const T *t0[ZB], *t1[ZB];
+#pragma unroll
+    for (int z = 0; z < ZB; ++z) {
+        const int zz = (FULL || z < gn) ? z : 0;
+        cplane[z] = static_cast<T *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
+        t0[z] = sgpr(static_cast<const T *>(A.tile[zz]));
+        t1[z] = sgpr(static_cast<const T *>(A.ltile[zz]));
+    }
+    const float *flat = FLAT ? static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
+    const int ya = sgpr(A.first.b), xa = sgpr(A.first.c), yb = sgpr(A.seam.b), xb = sgpr(A.seam.c);
+    const int G = n / VEC + 1;   // upper bound of the whole groups of a row
+    for (int idx = tid; idx < rows * G; idx += 256) {
+        const int r = idx / G, j = idx - r * G;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        // the planes of a group sit at the same phase of a 128-byte line, so also of 16 bytes
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (VEC - 1));
+        const int v = (mis ? 1 : 0) + j;
+        if (v >= (n + mis) / VEC) continue;
+        const int p0 = v * VEC - mis;
+        const int y0 = ya + r, x0 = xa + p0, y1 = yb + r, x1 = xb + p0;
+        const int64_t s0 = (int64_t)y0 * P.tile_pitch + x0, s1 = (int64_t)y1 * P.tile_pitch + x1;
+        f32x4 ga0{}, ga1{}, gb0{}, gb1{};
+        if (FLAT) {
+            const float *gp0 = flat + (int64_t)y0 * P.tile_w + x0, *gp1 = flat + (int64_t)y1 * P.tile_w + x1;
+            ga0 = ldg<F32x4U>(gp0), ga1 = ldg<F32x4U>(gp0 + 4), gb0 = ldg<F32x4U>(gp1), gb1 = ldg<F32x4U>(gp1 + 4);
+        }
+        u32x4 ra[ZB], rb[ZB];
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                ra[z] = ldg<U32x4U>(t0[z] + s0);
+                rb[z] = ldg<U32x4U>(t1[z] + s1);
+            }
+        float g0[VEC], g1[VEC], r0[VEC], r1[VEC], w0[VEC], w1[VEC], ws[VEC], rw[VEC];
+        const int wy0 = min(y0 + 1, P.tile_h - y0), wy1 = min(y1 + 1, P.tile_h - y1);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (FLAT) {
+                g0[e] = e < 4 ? ga0[e & 3] : ga1[e & 3];
+                g1[e] = e < 4 ? gb0[e & 3] : gb1[e & 3];
+                r0[e] = recip_for<1>(g0[e]);
+                r1[e] = recip_for<1>(g1[e]);
+            }
+            w0[e] = (float)min(min(x0 + e + 1, P.tile_w - (x0 + e)), wy0);
+            w1[e] = (float)min(min(x1 + e + 1, P.tile_w - (x1 + e)), wy1);
+            ws[e] = __fadd_rn(w0[e], w1[e]);
+            rw[e] = recip_for<1>(ws[e]);
+        }
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                uint32_t k[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float va = (float)Pix<uint16_t>::get(ra[z], e), vb = (float)Pix<uint16_t>::get(rb[z], e);
+                    if (FLAT) {
+                        va = div_by_refined(va, g0[e], r0[e]);
+                        vb = div_by_refined(vb, g1[e], r1[e]);
+                    }
+                    const float acc = __fadd_rn(__fmul_rn(w0[e], va), __fmul_rn(w1[e], vb));
+                    k[e] = cvt_u32_sat(__builtin_rintf(div_by_refined(acc, ws[e], rw[e])));   // negative -> 0
+                }
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                u32x4 out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(k[2 * q], k[2 * q + 1]);   // saturates to 65535
+                    out[q] = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
+                }
+                stg_nt(cplane[z] + doff + p0, out);
+            }
+    }
+    // the pixels before / after the 16-byte-aligned body of each row, one per thread and plane
+    for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
+        const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (VEC - 1));
+        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int p = -1;
+        if (l < VEC) {
+            if (l < head_end) p = l;
+        } else if (tail_start + (l - VEC) < n) {
+            p = tail_start + (l - VEC);
+        }
+        if (p < 0) continue;
+        const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
+        const float ga = FLAT ? ldg_s<float>(flat + (int64_t)y0 * P.tile_w + x0) : 1.0f, gb = FLAT ? ldg_s<float>(flat + (int64_t)y1 * P.tile_w + x1) : 1.0f;
+        const float fa = FLAT ? recip_for<1>(ga) : 1.0f, fb = FLAT ? recip_for<1>(gb) : 1.0f;
+        const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
+        const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
+        const float wsum = __fadd_rn(wa, wb), rws = recip_for<1>(wsum);
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                float va = (float)ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0), vb = (float)ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
+                if (FLAT) {
+                    va = div_by_refined(va, ga, fa);
+                    vb = div_by_refined(vb, gb, fb);
+                }
+                const float acc = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
+                stg_s<T>(cplane[z] + doff + p, (T)min(cvt_u32_sat(__builtin_rintf(div_by_refined(acc, wsum, rws))), 65535u));
+            }
+    }
+}
+
+// waves per SIMD asked of the register allocator: with gains 3 (168 VGPRs instead of 171: 0.555 against 0.532 for 2 waves,
+// 4 waves / 128 VGPRs 0.551); without gains the allocator's own choice measured best (0.588 against 0.574 / 0.581 at 3 / 4)
+#ifndef SQ_WAVES_FEATHER_ZG
+#define SQ_WAVES_FEATHER_ZG 3
+#endif
+template <int FLAT, bool DYN>
+__global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feather_zg_kernel(const FuseParams P, const int64_t n_items) {
+    typedef uint16_t T;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_groups = *P.n_groups;
+    auto pre = [&](int unit, const Item &it, int64_t) -> UnitAux {
+        UnitAux A;
+        A.g = P.groups[unit];
+        A.seam = Seam{-1, 0, 0, 0};
+        A.first = Seam{-1, 0, 0, 0};
+        const bool one = it.nref >= 1 && it.nref <= 2, two = it.nref == 2;
+        Ref ra{}, rb{};
+        if (one) {
+            ra = P.refs[it.a];
+            A.first = Seam{ra.tile, ra.src_y + it.b, ra.src_x + it.c, 0};
+        }
+        if (two) {
+            rb = P.refs[it.a + 1];
+            A.seam = Seam{rb.tile, rb.src_y + it.b, rb.src_x + it.c, 0};
+        }
+#pragma unroll
+        for (int z = 0; z < ZB; ++z) {
+            A.tile[z] = (one && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], ra.tile) : nullptr;
+            A.ltile[z] = (two && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], rb.tile) : nullptr;
+        }
+        return A;
+    };
+    auto body = [&](int, const Item &it, const UnitAux &A) {
+        const int gn = sgpr(A.g.n);
+        if (gn == 1) {
+            feather_one_item<T, T, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
+        } else if (it.nref <= 1) {
+            Item one = it;
+            one.a = sgpr(A.first.a);
+            one.b = sgpr(A.first.b);
+            one.c = sgpr(A.first.c);
+            if (!FLAT) {   // nothing to share: the plain pipelined copy, plane after plane
+                for (int z = 0; z < gn; ++z)
+                    process_item<T, 0, 1>(P, sgpr(A.g.plane[z]), one, sgpr(static_cast<const T *>(A.tile[z])), wave, lane);
+            } else if (gn == ZB) {
+                process_item_zg<true, 1>(P, A, gn, one, wave, lane);
+            } else {
+                process_item_zg<false, 1>(P, A, gn, one, wave, lane);
+            }
+        } else if (it.nref == 2) {
+            if (gn == ZB) blend_item_zg<FLAT, true>(P, A, gn, it, threadIdx.x);
+            else blend_item_zg<FLAT, false>(P, A, gn, it, threadIdx.x);
+        } else {
+            for (int z = 0; z < gn; ++z) blend_item<T, T, FLAT, true>(P, sgpr(A.g.plane[z]), it, threadIdx.x);
+        }
+    };
+    if (DYN) {
+        for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);
+    } else {
+        __shared__ Item s_it;
+        __shared__ UnitAux s_A;
+        const int64_t n_work = (int64_t)n_groups * n_items;
+        for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int unit = (int)(work / n_items);
+                s_it = P.items[work - unit * n_items];
+                s_A = pre(unit, s_it, work - unit * n_items);
+            }
+            __syncthreads();
+            body(0, sgpr(s_it), s_A);
+        }
+    }
+}
 
 // Persistent launch: as many workgroups as the chip keeps resident (queried once per kernel),
 // each walking the (plane, item) list with a grid stride.
@@ -1242,14 +1458,17 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
     const G *f = static_cast<const G *>(flat_ptrs[plane]);
     if (!f) return;
     const G lo = (G)__builtin_ldexp(1.0, FAST_MIN_EXP), hi = (G)__builtin_ldexp(1.0, FAST_END_EXP);
-    bool odd = false;
+    const G mlo = (G)__builtin_ldexp(1.0, -MODERATE_EXP), mhi = (G)__builtin_ldexp(1.0, MODERATE_EXP);
+    bool odd = false, wide = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     {
         const G g = ldg_s<G>(f + i);
         const G a = g < 0 ? -g : g;
         odd |= !(a >= lo && a < hi);   // NaN fails both
+        wide |= !(a >= mlo && a < mhi);
     }
-    if (__builtin_amdgcn_ballot_w64(odd) && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], 1u);
+    const uint32_t bits = (__builtin_amdgcn_ballot_w64(odd) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(wide) ? 2u : 0u);
+    if (bits && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], bits);
 }
 
 // exhaustive check of the fast divide against the IEEE path: final clipped integers, one binade of
@@ -1301,6 +1520,37 @@ extern "C" int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int3
         e = hipGetLastError();
     }
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_flat_divide: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
+
+// the grouped feather blend's division acc / wsum (div_by_refined with recip_for<1>(wsum)) against the compiler's IEEE
+// division: every mantissa of acc in one binade per blockIdx.y, every weight sum the kernel can meet
+__global__ __launch_bounds__(256) void selftest_blend_divide_kernel(int exponent0, int negative, unsigned long long *bad) {
+    const uint32_t mant = blockIdx.x * 256u + threadIdx.x;   // 2^23 mantissas
+    const int exponent = exponent0 + (int)blockIdx.y;
+    const float acc = __uint_as_float(((uint32_t)(exponent + 127) << 23) | mant | (negative ? 0x80000000u : 0u));
+    unsigned long long local = 0;
+    for (int ws = 2; ws <= BLEND_WSUM_MAX; ++ws) {
+        const float d = (float)ws;
+        const float want = __fdiv_rn(acc, d), got = div_by_refined(acc, d, recip_for<1>(d));
+        local += __float_as_uint(want) != __float_as_uint(got);
+    }
+    if (local) atomicAdd(bad, local);
+}
+
+extern "C" int sq_selftest_blend_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
+                                        void *stream) {
+    if (!mismatches_dev || exponent < BLEND_ACC_MIN_EXP || n_binades < 1 || exponent + n_binades > BLEND_ACC_END_EXP)
+        return fail(SQ_ERR_INVALID, "sq_selftest_blend_divide: binades [%d, %d] outside the blend's range [%d, %d]", exponent,
+                    exponent + n_binades - 1, BLEND_ACC_MIN_EXP, BLEND_ACC_END_EXP - 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(mismatches_dev, 0, sizeof(uint64_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_blend_divide_kernel, dim3(1u << 15, n_binades), dim3(256), 0, s, exponent, negative,
+                           reinterpret_cast<unsigned long long *>(mismatches_dev));
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_blend_divide: %s", hipGetErrorString(e));
     return SQ_OK;
 }
 
@@ -1464,7 +1714,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             char *sc = static_cast<char *>(a->scratch_dev);
             uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
             PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
-            hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, a->n_planes,
+            hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 1u, a->n_planes,
                                a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
             P.groups = groups;
             P.n_groups = n_groups;
@@ -1496,6 +1746,24 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (flat == 1) SQ_FEATHER_F(T, O, 1); \
         SQ_FEATHER_F(T, O, 2);           \
     } while (0)
+    if (u16 && !f32out && flat != 2 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS) &&
+        std::min(a->tile_h, a->tile_w) <= BLEND_WSUM_MAX) {   // a weight is at most half the shorter tile side, a weight sum twice that
+        // planes that share a gain image (every gain moderate), or that have none, go through the items together
+        // (fuse_feather_zg_kernel)
+        char *sc = static_cast<char *>(a->scratch_dev);
+        uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
+        PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
+        hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 3u, a->n_planes,
+                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
+        P.groups = groups;
+        P.n_groups = n_groups;
+        if (flat == 1) {
+            if (P.queue) return launch_zg(fuse_feather_zg_kernel<1, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            return launch_zg(fuse_feather_zg_kernel<1, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        }
+        if (P.queue) return launch_zg(fuse_feather_zg_kernel<0, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        return launch_zg(fuse_feather_zg_kernel<0, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+    }
     if (u16) {
         if (f32out) SQ_FEATHER(uint16_t, float);
         SQ_FEATHER(uint16_t, uint16_t);

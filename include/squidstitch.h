@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 102 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit, sq_blosc_* */
+#define SQ_VERSION 103 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit, sq_blosc_* */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -268,6 +268,14 @@ int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negativ
  * included) x all 65536 numerators; compares the quotient doubles and the clipped integers. */
 int sq_selftest_flat_divide_f64(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t seed,
                                 uint64_t *mismatches_dev, void *stream);
+
+/* The grouped feather blend divides the weighted sum of two quotients by the sum of their weights with the IEEE
+ * sequence minus its range handling (the reciprocal of the weight sum is shared by the planes of a group).  This
+ * compares it with the compiler's division, bit for bit, for ALL 2^23 mantissas of the numerator in n_binades
+ * consecutive binades starting at 2^exponent (allowed: -44..52, what moderate gains can produce) x every weight sum
+ * 2..16384, either sign; *mismatches_dev must come back 0. */
+int sq_selftest_blend_divide(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t *mismatches_dev,
+                             void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic tiles on the device (bench / tests only): the generator of

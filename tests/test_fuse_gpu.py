@@ -191,6 +191,21 @@ def test_fast_flatfield_divide_is_exact_exhaustively():
         native.selftest_flat_divide(-101, 1, False, dev)
 
 
+def test_grouped_blend_division_equals_ieee_exhaustively():
+    """Feather mode with plane groups divides the weighted sum by the weight sum with a reciprocal shared by the planes
+    of the group: the IEEE sequence without its range handling.  Bit-equal to the compiler's division for every
+    numerator (all 2^23 mantissas of the 97 binades 2^-44..2^52 that moderate gains can produce, both signs in a spread
+    of them) and every weight sum 2..16384: 1.3e13 quotients."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    for e0 in range(-44, 53, 8):
+        assert native.selftest_blend_divide(e0, min(8, 53 - e0), False, dev) == 0, e0
+    for e0 in (-44, -1, 0, 16, 52):
+        assert native.selftest_blend_divide(e0, 1, True, dev) == 0, e0
+    with pytest.raises(native.NativeError, match='outside'):
+        native.selftest_blend_divide(53, 1, False, dev)
+
+
 def test_flatfield_fast_and_slow_paths_mix_in_one_vector():
     """Gains that leave the fast range (0, denormal, huge, inf, NaN, negative) sit next to ordinary
     ones inside the same 8-pixel vectors."""

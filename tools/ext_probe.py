@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from image_stitcher_amd import native, placement, registration, synth
 dev = torch.device('cuda:0')
-g, T, OV, P = 16, 2048, 244, 4
+g, T, OV, P = 16, 2048, 244, int(os.environ.get('SQ_EXT_PLANES', '4'))
 spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=OV, ov_x=OV, seed=5)
 tiles = torch.empty((P, g * g, T, T), dtype=torch.uint16, device=dev)
 for p in range(P):
@@ -35,6 +35,11 @@ for dt, flats in ((torch.uint16, None), (torch.uint16, [ff] * P), (torch.float32
     alg = P * hc * wc * (2 * rho + canvas.element_size())       # 2*rho B read + the voxel written
     print(f'feather -> {dt}{" with float32 gains" if flats else ""}: {t*1e3:.2f} ms for {P} planes -> '
           f'{P*hc*wc/t/1e6:.0f} Mvoxel/s, {alg/t/1e9:.0f} GB/s algorithmic ({alg/t/8e12:.3f} of 8 TB/s)')
+    if flats and os.environ.get('SQ_EXT_AB'):   # plane groups against one plane at a time, same buffers, alternating
+        for rnd in range(3):
+            for fl in (0, native.SQ_FUSE_NO_PLANE_GROUPS):
+                t = timeit(lambda: native.fuse_planes(plan, tiles, canvas, flats, flags=fl))
+                print(f'  round {rnd} flags {fl}: {t*1e3:.2f} ms ({alg/t/8e12:.3f} of 8 TB/s)', flush=True)
     del canvas
 if os.environ.get('SQ_EXT_FEATHER_ONLY'):
     sys.exit(0)

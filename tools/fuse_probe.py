@@ -26,16 +26,18 @@ def main():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ab', type=int, default=None, help='also time these flags, alternating with --flags in the same process (same buffers)')
     ap.add_argument('--libs', default=None, help='comma-separated build variants (tools/build_variant.sh names, or "default") timed alternately in this process on the same buffers')
+    ap.add_argument('--feather', action='store_true', help='feather plan (uncropped rectangles, blended overlaps)')
     ap.add_argument('--canvas-first', action='store_true', help='allocate the canvas before the tiles')
     ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     g, T = a.grid, a.tile
     shifts = placement.Shifts((a.drift[0], -a.ov), (-a.ov, a.drift[1]))
-    rects = placement.grid_rects(g, g, T, T, shifts)
+    rects = placement.grid_rects(g, g, T, T, shifts, crop=not a.feather)
+    MODE = native.SQ_FUSE_FEATHER if a.feather else native.SQ_FUSE_OVERWRITE
     wc, hc = placement.canvas_size(g, g, T, T, use_registration=True, shifts=shifts)
     t0 = time.time()
-    plan = native.FusePlan(rects, T, T, hc, wc)
+    plan = native.FusePlan(rects, T, T, hc, wc, MODE)
     print(f'plan: {plan.n_spans} spans, {plan.n_items} items, table {plan.table.nbytes/1e6:.2f} MB, '
           f'{time.time()-t0:.3f}s; canvas {hc}x{wc}; covered {plan.covered_voxels/(hc*wc):.3f}')
     spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=a.ov, ov_x=a.ov, seed=1)
@@ -72,11 +74,14 @@ def main():
     ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
     vox = a.planes * hc * wc
     alg = a.planes * (plan.covered_voxels * 4 + (hc * wc - plan.covered_voxels) * 2)
+    if a.feather:   # every tile pixel read once + the voxel written
+        alg = a.planes * (a.grid * a.grid * T * T * 2 + hc * wc * 2)
     if a.check:
         from oracle import stitch_oracle as O
-        want = O.fuse_plane_overwrite(list(tiles[0].cpu().numpy()), rects, hc, wc, None if flats is None else g)
+        fuse_o = (lambda t, r, h, w, f: O.fuse_plane_feather(t, r, h, w, f, out_dtype=np.uint16)) if a.feather else O.fuse_plane_overwrite
+        want = fuse_o(list(tiles[0].cpu().numpy()), rects, hc, wc, None if flats is None else g)
         for p in sorted({0, a.planes - 1}):
-            want_p = want if p == 0 else O.fuse_plane_overwrite(list(tiles[p].cpu().numpy()), rects, hc, wc, None if flats is None else g)
+            want_p = want if p == 0 else fuse_o(list(tiles[p].cpu().numpy()), rects, hc, wc, None if flats is None else g)
             print(f'plane {p} mismatched voxels vs oracle:', int(np.count_nonzero(canvas[p].cpu().numpy() != want_p)))
     print(f'fuse: {ms.mean():.3f} ms (min {ms.min():.3f}) -> {vox/ms.mean()/1e3:.1f} Mvoxel/s, '
           f'{alg/ms.mean()/1e6:.1f} GB/s algorithmic ({alg/ms.mean()/1e6/8000:.3f} of 8 TB/s)')
@@ -91,7 +96,7 @@ def main():
                 getattr(h, fn).argtypes = args
             handles[name] = h
             native._lib = h
-            plans[name] = native.FusePlan(rects, T, T, hc, wc)
+            plans[name] = native.FusePlan(rects, T, T, hc, wc, MODE)
         for rnd in range(4):
             for name in handles:
                 native._lib = handles[name]
