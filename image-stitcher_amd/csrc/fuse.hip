@@ -674,20 +674,56 @@ __device__ __forceinline__ float quot_one(float n, float g, float r) {
     if (RND) q = __builtin_rintf(fmaf(fmaf(-g, q, n), r, q));
     return q;
 }
+// float64 gains (overwrite mode): the arithmetic of div_u16_normal_f64 with its reciprocal -- v_rcp_f64 and two Newton
+// steps, 5 of its 8 instructions -- hoisted out of the planes' loop
+__device__ __forceinline__ double recip_f64(double g) {
+    double r = __builtin_amdgcn_rcp(g);
+    r = fma(r, fma(-g, r, 1.0), r);
+    return fma(r, fma(-g, r, 1.0), r);
+}
 template <int RND>
-__device__ __forceinline__ uint32_t quot_pair(uint32_t word, float g_lo, float g_hi, float r_lo, float r_hi) {
-    const float n0 = (float)(word & 0xFFFFu), n1 = (float)(word >> 16);
-    const uint32_t a = cvt_u32_sat(quot_one<RND>(n0, g_lo, r_lo));
-    const uint32_t b = cvt_u32_sat(quot_one<RND>(n1, g_hi, r_hi));
+__device__ __forceinline__ float recip_of(float g) { return recip_for<RND>(g); }
+template <int RND>
+__device__ __forceinline__ double recip_of(double g) { return recip_f64(g); }
+template <int RND>
+__device__ __forceinline__ float quot_of(float n, float g, float r) { return quot_one<RND>(n, g, r); }
+template <int RND>
+__device__ __forceinline__ double quot_of(double n, double g, double r) {
+    const double q = n * r;
+    return fma(fma(-g, q, n), r, q);
+}
+template <int RND, typename G>
+__device__ __forceinline__ uint32_t quot_pair(uint32_t word, G g_lo, G g_hi, G r_lo, G r_hi) {
+    const G n0 = (G)(word & 0xFFFFu), n1 = (G)(word >> 16);
+    const uint32_t a = cvt_u32_sat(quot_of<RND>(n0, g_lo, r_lo));
+    const uint32_t b = cvt_u32_sat(quot_of<RND>(n1, g_hi, r_hi));
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
+// 8 consecutive gains at any alignment
+__device__ __forceinline__ void load_gains(const char *p, float (&g)[8]) {
+    const f32x4 a = ldg<F32x4U>(p), b = ldg<F32x4U>(p + 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        g[e] = a[e];
+        g[4 + e] = b[e];
+    }
+}
+__device__ __forceinline__ void load_gains(const char *p, double (&g)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f64x2 a = ldg<F64x2U>(p + 16 * q);
+        g[2 * q] = a[0];
+        g[2 * q + 1] = a[1];
+    }
+}
 
-template <bool FULL, int RND = 0>
+template <bool FULL, int RND = 0, typename G = float>
 __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
                                                 const int wave, const int lane) {
     typedef uint16_t T;
+    constexpr uint32_t GSZ = sizeof(G);
     constexpr int VEC = 8, LINE = 64;
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
@@ -712,15 +748,15 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                 const bool left = p < 0;
                 const int po = left ? p : -1;
                 const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
-                const float *lflat = static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
-                const float eg = ldg_s<float>(reinterpret_cast<const char *>(lflat + (int64_t)(sb + r) * P.tile_w + sc) + po * 4);
-                const float er = recip_for<RND>(eg);
+                const G *lflat = static_cast<const G *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+                const G eg = ldg_s<G>(reinterpret_cast<const char *>(lflat + (int64_t)(sb + r) * P.tile_w + sc) + po * (int)GSZ);
+                const G er = recip_of<RND>(eg);
 #pragma unroll
                 for (int z = 0; z < ZB; ++z)
                     if (FULL || z < gn) {
                         const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
                         const T e = ldg_s<T>(reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc) + po * 2);
-                        const uint32_t kq = left ? min(cvt_u32_sat(quot_one<RND>((float)e, eg, er)), 65535u) : 0u;
+                        const uint32_t kq = left ? min(cvt_u32_sat(quot_of<RND>((G)e, eg, er)), 65535u) : 0u;
                         stg_s<T>(reinterpret_cast<char *>(cplane[z] + doff) + p * 2, (T)kq);
                     }
             }
@@ -735,7 +771,7 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         }
         return;
     }
-    const float *flat = static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+    const G *flat = static_cast<const G *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
     for (int r = wave; r < rows; r += 4) {
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
         const int64_t soff = (int64_t)(it.b + r) * P.tile_pitch + it.c;
@@ -763,25 +799,20 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             const bool act = v >= v_first && v < v_end;
             const int p0 = v * VEC - mis;
             const uint32_t o = (uint32_t)min(max(p0, 0), n - VEC);   // clamped: v_end > v_first implies n >= VEC; == p0 where act
-            const f32x4 g0 = ldg<F32x4U>(frow + o * 4u), g1 = ldg<F32x4U>(frow + o * 4u + 16u);
+            G g[8], rc[8];
+            load_gains(frow + o * GSZ, g);
             u32x4 px[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) px[z] = ldg<U32x4U>(srow[z] + o * 2u);
-            f32x4 r0, r1;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                r0[c] = recip_for<RND>(g0[c]);
-                r1[c] = recip_for<RND>(g1[c]);
-            }
+            for (int c = 0; c < 8; ++c) rc[c] = recip_of<RND>(g[c]);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
                     u32x4 ov;
-                    ov[0] = quot_pair<RND>(px[z][0], g0[0], g0[1], r0[0], r0[1]);
-                    ov[1] = quot_pair<RND>(px[z][1], g0[2], g0[3], r0[2], r0[3]);
-                    ov[2] = quot_pair<RND>(px[z][2], g1[0], g1[1], r1[0], r1[1]);
-                    ov[3] = quot_pair<RND>(px[z][3], g1[2], g1[3], r1[2], r1[3]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ov[c] = quot_pair<RND, G>(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
                     if (act) stg_nt_at(drow[z], o * 2u, ov);
                 }
         }
@@ -793,7 +824,7 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
             const int po = (left && lzero) ? 0 : p;   // left of a zero-fill seam: any valid address, the value is replaced
             const char *lfrow = lzero ? frow : reinterpret_cast<const char *>(flat + (int64_t)(sb + r) * P.tile_w + sc);
-            const float eg = ldg_s<float>((left ? lfrow : frow) + po * 4);
+            const G eg = ldg_s<G>((left ? lfrow : frow) + po * (int)GSZ);
             T e[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
@@ -802,11 +833,11 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                     const char *lrow = lzero ? srow[z] : reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc);
                     e[z] = ldg_s<T>((left ? lrow : srow[z]) + po * 2);
                 }
-            const float er = recip_for<RND>(eg);
+            const G er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
+                    uint32_t kq = min(cvt_u32_sat(quot_of<RND>((G)e[z], eg, er)), 65535u);
                     if (left && lzero) kq = 0;
                     stg_s<T>(drow[z] + p * 2, (T)kq);
                 }
@@ -824,16 +855,16 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         }
         if (__builtin_amdgcn_ballot_w64(ep >= 0)) {   // wave-uniform: many rows have no edge pixels at all
             const uint32_t eo = (uint32_t)max(ep, 0);
-            const float eg = ldg_s<float>(frow + eo * 4u);
+            const G eg = ldg_s<G>(frow + eo * GSZ);
             T e[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) e[z] = ldg_s<T>(srow[z] + eo * 2u);
-            const float er = recip_for<RND>(eg);
+            const G er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    const uint32_t kq = min(cvt_u32_sat(quot_one<RND>((float)e[z], eg, er)), 65535u);
+                    const uint32_t kq = min(cvt_u32_sat(quot_of<RND>((G)e[z], eg, er)), 65535u);
                     if (ep >= 0) stg_s<T>(drow[z] + eo * 2u, (T)kq);
                 }
         }
@@ -843,9 +874,10 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
 #ifndef SQ_WAVES_ZG
 #define SQ_WAVES_ZG 1
 #endif
-template <bool DYN>
+template <typename G, bool DYN>
 __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(const FuseParams P, const int64_t n_items) {
     typedef uint16_t T;
+    constexpr int FLAT = sizeof(G) == 8 ? 2 : 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = *P.n_groups;
@@ -864,11 +896,11 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
     auto body = [&](int, const Item &it, const UnitAux &A) {
         const int gn = sgpr(A.g.n);
         if (gn == 1) {   // (a group of one through process_item_zg, seam owners included, measured the same: 0.514 / 0.514)
-            process_item<T, 1>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
+            process_item<T, FLAT>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
         } else if (gn == ZB) {
-            process_item_zg<true>(P, A, gn, it, wave, lane);
+            process_item_zg<true, 0, G>(P, A, gn, it, wave, lane);
         } else {
-            process_item_zg<false>(P, A, gn, it, wave, lane);
+            process_item_zg<false, 0, G>(P, A, gn, it, wave, lane);
         }
     };
     if (DYN) {
@@ -1709,7 +1741,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);     \
         return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                 \
     } while (0)
-        if (u16 && flat == 1 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
+        if (u16 && flat && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
             // planes that share a gain image go through the items together (fuse_overwrite_zg_kernel)
             char *sc = static_cast<char *>(a->scratch_dev);
             uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
@@ -1718,8 +1750,12 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
                                a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
             P.groups = groups;
             P.n_groups = n_groups;
-            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-            return launch_zg(fuse_overwrite_zg_kernel<false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            if (flat == 2) {
+                if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<double, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+                return launch_zg(fuse_overwrite_zg_kernel<double, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            }
+            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<float, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            return launch_zg(fuse_overwrite_zg_kernel<float, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
         }
         if (u16) {
             if (flat == 0) SQ_OVERWRITE(uint16_t, 0);

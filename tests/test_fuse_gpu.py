@@ -444,8 +444,12 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
     cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
     planes = int(rng.integers(1, 13))
     tiles = rng.integers(0, 65536, size=(planes, n, th, tw)).astype(np.uint16)
-    gains = [np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float32) for _ in range(3)]
+    # overwrite mode, odd seeds: float64 gains (their plane groups share the float64 reciprocals)
+    gdtype = np.float64 if (mode == native.SQ_FUSE_OVERWRITE and seed % 2) else np.float32
+    gains = [np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(gdtype) for _ in range(3)]
     gains[2][rng.integers(0, th), rng.integers(0, tw)] = 0.0            # this image needs the generic divide
+    if mode == native.SQ_FUSE_FEATHER:
+        gains[1][rng.integers(0, th), rng.integers(0, tw)] = 2.0 ** -30  # not moderate: no grouped blend for its planes
     which = [int(rng.integers(0, 3)) if rng.random() > 0.1 else -1 for _ in range(planes)]
     if planes >= 7:
         which[:6] = [0] * 6                                              # a full group of 5 and a leftover
@@ -473,9 +477,10 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('gdtype', [np.float32, np.float64], ids=['f32', 'f64'])
 @pytest.mark.parametrize('queues', [False, True], ids=['static', 'queues'])
 @pytest.mark.parametrize('seed', range(5))
-def test_seam_lines_have_one_writer(seed, queues):
+def test_seam_lines_have_one_writer(seed, queues, gdtype):
     """Plane groups, tiles at least a cache line wide either side of every vertical seam: the item right of a seam writes
     the whole 128-byte line the seam falls in (pixels of BOTH tiles, or zero fill on the left), the item left of it stops
     at the line boundary (Seam in csrc/common.h).  Canvas pitches that put every row at a different phase, pitches that
@@ -499,7 +504,7 @@ def test_seam_lines_have_one_writer(seed, queues):
     cw = int((rects[:, 5] + rects[:, 3]).max()) + int(rng.integers(0, 140))
     planes = int(rng.integers(2, 8))
     tiles = rng.integers(0, 65536, size=(planes, len(rects), th, tw)).astype(np.uint16)
-    gain = np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float32)
+    gain = np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(gdtype)
     d_gain = torch.from_numpy(gain).to(dev)
     d_tiles = torch.from_numpy(tiles).to(dev)
     plan = native.FusePlan(rects, th, tw, ch, cw)
