@@ -33,7 +33,7 @@ from .omezarr import write_ome_zarr
 from .ometiff import write_ome_tiff
 from .placement import Shifts
 from .stitcher_parameters import StitchingParameters
-from .tiffio import read_image
+from .tiffio import read_image, read_image_into
 
 _IMAGE_EXT = ('.bmp', '.tiff', 'tif', 'jpg', 'jpeg', 'png')   # as the reference spells them (stitcher.py:169)
 
@@ -712,6 +712,8 @@ class Stitcher:
 
                     def load(job, host=host):
                         pi, ti, (info, rgb, _) = job
+                        if rgb < 0 and read_image_into(info['filepath'], host[pi, ti]):
+                            return      # file -> page-locked staging in one read
                         img = read_image(info['filepath'])
                         if rgb >= 0:
                             img = img[:, :, rgb]

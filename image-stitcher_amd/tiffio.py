@@ -71,25 +71,33 @@ def write_tiff(path: str, img: np.ndarray) -> None:
         fh.write(b''.join(out))
 
 
-def _read_baseline_tiff(buf: bytes):
-    bo = {b'II': '<', b'MM': '>'}.get(buf[:2])
-    if bo is None or struct.unpack(bo + 'H', buf[2:4])[0] != 42:
+def _parse_ifd(get):
+    """First IFD of a classic TIFF through ``get(offset, nbytes) -> bytes``: (byte order, {tag: values}) or None."""
+    head = get(0, 8)
+    bo = {b'II': '<', b'MM': '>'}.get(head[:2])
+    if bo is None or len(head) < 8 or struct.unpack(bo + 'H', head[2:4])[0] != 42:
         return None
-    (ifd,) = struct.unpack(bo + 'I', buf[4:8])
-    (n,) = struct.unpack(bo + 'H', buf[ifd:ifd + 2])
+    (ifd,) = struct.unpack(bo + 'I', head[4:8])
+    (n,) = struct.unpack(bo + 'H', get(ifd, 2))
+    table = get(ifd + 2, 12 * n)
     tags = {}
     for i in range(n):
-        e = ifd + 2 + 12 * i
-        tag, typ, cnt = struct.unpack(bo + 'HHI', buf[e:e + 8])
+        e = 12 * i
+        tag, typ, cnt = struct.unpack(bo + 'HHI', table[e:e + 8])
         if typ not in (1, 3, 4):
             continue
         sz = _SIZES[typ] * cnt
         if sz <= 4:
-            raw = buf[e + 8:e + 8 + sz]
+            raw = table[e + 8:e + 8 + sz]
         else:
-            (off,) = struct.unpack(bo + 'I', buf[e + 8:e + 12])
-            raw = buf[off:off + sz]
+            (off,) = struct.unpack(bo + 'I', table[e + 8:e + 12])
+            raw = get(off, sz)
         tags[tag] = struct.unpack(bo + _TYPES[typ] * cnt, raw)
+    return bo, tags
+
+
+def _layout(bo, tags):
+    """(h, w, samples per pixel, dtype, strip offsets, strip byte counts) of an uncompressed chunky 8/16-bit image, or None."""
     if tags.get(259, (1,))[0] != 1 or 273 not in tags:
         return None
     w, h = tags[256][0], tags[257][0]
@@ -98,14 +106,60 @@ def _read_baseline_tiff(buf: bytes):
     if bits not in (8, 16) or tags.get(339, (1,))[0] != 1 or tags.get(284, (1,))[0] != 1:
         return None
     dt = np.dtype(bo + ('u1' if bits == 8 else 'u2'))
-    counts = tags.get(279)
-    parts = []
-    for i, off in enumerate(tags[273]):
-        cnt = counts[i] if counts else h * w * spp * dt.itemsize
-        parts.append(buf[off:off + cnt])
+    offsets = tags[273]
+    counts = tags.get(279) or (h * w * spp * dt.itemsize,)
+    if len(counts) != len(offsets):
+        return None
+    return h, w, spp, dt, offsets, counts
+
+
+def _read_baseline_tiff(buf: bytes):
+    parsed = _parse_ifd(lambda off, n: buf[off:off + n])
+    lay = parsed and _layout(*parsed)
+    if not lay:
+        return None
+    h, w, spp, dt, offsets, counts = lay
+    parts = [buf[off:off + cnt] for off, cnt in zip(offsets, counts)]
     arr = np.frombuffer(b''.join(parts), dtype=dt, count=h * w * spp)
     arr = arr.astype(dt.newbyteorder('='))
     return arr.reshape((h, w) if spp == 1 else (h, w, spp))
+
+
+def read_image_into(path: str, out: np.ndarray) -> bool:
+    """Decode a tile file STRAIGHT INTO ``out`` (e.g. a slice of a page-locked staging buffer): the pixel bytes go from
+    the file to their destination in one ``readinto`` -- no intermediate ``bytes``, no copy that holds the interpreter
+    lock (``read_image`` makes four 8 MiB copies per 2048x2048 tile, most of them under the lock, which is what bounded
+    the threaded ingest).  Handles what Squid writes: an uncompressed, chunky, native-endian 8/16-bit TIFF whose strips
+    follow each other in the file, of exactly ``out``'s shape and dtype.  Returns False (``out`` untouched) for anything
+    else; the caller falls back to ``read_image``."""
+    if not path.lower().endswith(('.tif', '.tiff')) or not out.flags.c_contiguous or not out.flags.writeable:
+        return False
+    with open(path, 'rb', buffering=0) as fh:
+        def get(off, n):
+            fh.seek(off)
+            return fh.read(n)
+        try:
+            parsed = _parse_ifd(get)
+        except struct.error:
+            return False
+        lay = parsed and _layout(*parsed)
+        if not lay:
+            return False
+        h, w, spp, dt, offsets, counts = lay
+        shape = (h, w) if spp == 1 else (h, w, spp)
+        if tuple(out.shape) != shape or out.dtype != dt.newbyteorder('=') or (dt.itemsize > 1 and not dt.isnative):
+            return False
+        if sum(counts) != out.nbytes or any(offsets[i] + counts[i] != offsets[i + 1] for i in range(len(offsets) - 1)):
+            return False
+        view = memoryview(out).cast('B')
+        fh.seek(offsets[0])
+        got = 0
+        while got < len(view):
+            k = fh.readinto(view[got:])
+            if not k:
+                raise ValueError(f"{path}: truncated TIFF ({got} of {len(view)} pixel bytes)")
+            got += k
+    return True
 
 
 def read_image(path: str) -> np.ndarray:

@@ -55,6 +55,83 @@ def test_tiff_roundtrip(tmp_path):
         tiffio.write_tiff(str(tmp_path / 'b.tiff'), np.zeros((4, 4), np.float32))
 
 
+def _strip_tiff(arr, rows_per_strip, big_endian=False, ifd_last=True, gap=0):
+    """An uncompressed TIFF the way libtiff lays it out: strips of a few rows first, the IFD (with its offset / count
+    arrays) after the pixel data; ``gap`` bytes between two strips make them non-contiguous."""
+    import struct
+    bo = '>' if big_endian else '<'
+    h, w = arr.shape
+    data = arr.astype(arr.dtype.newbyteorder(bo)).tobytes()
+    row = w * arr.dtype.itemsize
+    strips = [data[r * row:(r + rows_per_strip) * row] for r in range(0, h, rows_per_strip)]
+    body, offs = b'', []
+    pos = 8
+    for i, st in enumerate(strips):
+        if i == 1 and gap:
+            body += b'\0' * gap
+            pos += gap
+        offs.append(pos)
+        body += st
+        pos += len(st)
+    n = len(strips)
+    ifd = pos
+    arrays_at = ifd + 2 + 9 * 12 + 4
+    ent = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, arr.dtype.itemsize * 8), (259, 3, 1, 1), (262, 3, 1, 1),
+           (273, 4, n, arrays_at if n > 1 else offs[0]), (277, 3, 1, 1), (278, 4, 1, rows_per_strip),
+           (279, 4, n, arrays_at + 4 * n if n > 1 else len(strips[0]))]
+    out = (b'MM' if big_endian else b'II') + struct.pack(bo + 'HI', 42, ifd) + body + struct.pack(bo + 'H', len(ent))
+    for tag, typ, cnt, val in ent:
+        out += struct.pack(bo + 'HHI', tag, typ, cnt) + (struct.pack(bo + 'HH', val, 0) if typ == 3 else struct.pack(bo + 'I', val))
+    out += struct.pack(bo + 'I', 0)
+    if n > 1:
+        out += struct.pack(bo + f'{n}I', *offs) + struct.pack(bo + f'{n}I', *[len(st) for st in strips])
+    return out
+
+
+def test_tiff_read_into_staging(tmp_path):
+    """``read_image_into`` puts a tile's pixels straight into the caller's buffer (the ingest's page-locked staging) for
+    the files Squid writes -- one strip or many contiguous ones, IFD before or after the data -- and declines, leaving
+    the buffer alone, for everything else (then ``read_image`` decodes it as before)."""
+    rng = np.random.default_rng(3)
+    a16 = rng.integers(0, 65536, (37, 53)).astype(np.uint16)
+    a8 = rng.integers(0, 256, (20, 31)).astype(np.uint8)
+    p = str(tmp_path / 't.tiff')
+    for arr in (a16, a8):
+        tiffio.write_tiff(p, arr)
+        stack = np.full((3,) + arr.shape, 7, arr.dtype)
+        assert tiffio.read_image_into(p, stack[1])
+        np.testing.assert_array_equal(stack[1], arr)
+        assert (stack[0] == 7).all() and (stack[2] == 7).all()
+        for rows in (1, 8, arr.shape[0]):
+            with open(p, 'wb') as fh:
+                fh.write(_strip_tiff(arr, rows))
+            out = np.zeros_like(arr)
+            assert tiffio.read_image_into(p, out)
+            np.testing.assert_array_equal(out, arr)
+            np.testing.assert_array_equal(tiffio.read_image(p), arr)
+    out = np.full_like(a16, 9)
+    with open(p, 'wb') as fh:
+        fh.write(_strip_tiff(a16, 8, big_endian=True))
+    assert not tiffio.read_image_into(p, out) and (out == 9).all()          # byte order: needs a swap
+    np.testing.assert_array_equal(tiffio.read_image(p), a16)
+    with open(p, 'wb') as fh:
+        fh.write(_strip_tiff(a16, 8, gap=6))
+    assert not tiffio.read_image_into(p, out) and (out == 9).all()          # strips not back to back
+    np.testing.assert_array_equal(tiffio.read_image(p), a16)
+    tiffio.write_tiff(p, a16)
+    assert not tiffio.read_image_into(p, np.zeros((37, 54), np.uint16))     # another shape
+    assert not tiffio.read_image_into(p, np.zeros((37, 53), np.uint8))      # another dtype
+    assert not tiffio.read_image_into(p, np.zeros((37, 106), np.uint16)[:, ::2])   # not contiguous
+    tiffio.write_tiff(p, rng.integers(0, 256, (12, 9, 3)).astype(np.uint8))
+    rgb = np.zeros((12, 9, 3), np.uint8)
+    assert tiffio.read_image_into(p, rgb)
+    np.testing.assert_array_equal(rgb, tiffio.read_image(p))
+    with open(p, 'wb') as fh:
+        fh.write(_strip_tiff(a16, 8)[:-900])                                  # pixel data cut short? no: the IFD is
+    assert not tiffio.read_image_into(p, np.zeros_like(a16))                # gone -> not decodable here
+    assert not tiffio.read_image_into(str(tmp_path / 'x.png'), np.zeros_like(a16))
+
+
 def test_omezarr_roundtrip(tmp_path):
     """Store layout and chunk writing; the pyramid levels are inputs here (the product computes them on
     the device, the oracle stands in for it on CPU)."""
