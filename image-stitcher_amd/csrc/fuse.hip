@@ -464,7 +464,7 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
 #ifndef SQ_RB_FLAT
 #define SQ_RB_FLAT 1   // with gains a wave pipelines one row at a time (measured 0.8 % faster than two: less row state)
 #endif
-    constexpr int RB = FLAT ? SQ_RB_FLAT : BLOCK_ROWS / 4;   // rows a wave pipelines together
+    constexpr int RB = FLAT ? SQ_RB_FLAT : (BLOCK_ROWS >= 4 ? BLOCK_ROWS / 4 : 1);   // rows a wave pipelines together
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;         // vectors per lane per row (+1: alignment phase)
     constexpr int NSTEP = RB * SLOTS;
     constexpr int WANT = FLAT == 0 ? SQ_DEPTH_PLAIN : (FLAT == 1 ? SQ_DEPTH_F32 : SQ_DEPTH_F64);
@@ -719,6 +719,10 @@ __device__ __forceinline__ void load_gains(const char *p, double (&g)[8]) {
     }
 }
 
+// (One row per workgroup -- wave w taking slot w, 2 + ZB loads and ZB stores per thread -- launched one-shot, the regime
+// in which a bare copy gains 10 %, was built and measured with groups of 5 / 3 / 2: 0.53 / 0.43 / 0.39 against 0.62-0.64
+// for this form on the same box; the descriptor, its LDS hand-over and the tile pointers cost more per 14-36 KB workgroup
+// than the access pattern gives back.  profiles/r02_exp20_row_per_workgroup.log)
 template <bool FULL, int RND = 0, typename G = float>
 __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
                                                 const int wave, const int lane) {
