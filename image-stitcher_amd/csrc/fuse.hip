@@ -287,15 +287,24 @@ struct Pix<uint8_t> {
 // before the first store); 1-2 with a flatfield, where registers buy occupancy that hides the
 // divide behind other waves' memory time.
 // A row's edges (canvas pixels before the first / after the last whole 16-byte vector) are done
-// one pixel per lane by lanes 0..2*VEC-1: one 2-byte load and one 2-byte store per wave and row.
+// one pixel per lane: the head with the row's first slot, the tail with its second -- one 2-byte load and
+// one 2-byte store per wave and row each.  Where the item owns the seam on its left (Seam in common.h;
+// uint16 only: a line is 64 pixels = the wave) the head is the seam's whole line: lane j writes byte 2j
+// of it, the pixels before the item's first from the left neighbour's tile (or zero fill).
+constexpr int NO_EDGE = -(1 << 20);
 template <typename T>
 struct Row {
     T *drow;
     const T *srow;
     const char *frow;
+    const T *lsrow;       // seam owner: the left neighbour's pixel that would land on drow[0] ...
+    const char *lfrow;    // ... and its gain
     int mis, n;
     int v_first, v_end;   // whole vectors are v in [v_first, v_end)
-    int edge_p;           // this lane's edge pixel (or -1)
+    int edge_p;           // this lane's head pixel: before the first whole vector, or lane - mis over the seam's line
+                          // (< 0: the left neighbour's); NO_EDGE: none
+    int tail_p;           // this lane's pixel after the last whole vector (or -1)
+    bool lzero;           // the left neighbour is zero fill
 };
 
 template <typename T, int FLAT>
@@ -310,7 +319,7 @@ struct Slot {
 };
 
 template <typename T>
-__device__ __forceinline__ void row_setup(Row<T> &J, int lane) {
+__device__ __forceinline__ void row_setup(Row<T> &J, int lane, int seam_flags = 0) {
     constexpr int VEC = Pix<T>::N;
     // Vector v covers row pixels [v*VEC - mis, +VEC).  mis is the row's phase inside a 128-byte
     // line, not just inside 16 bytes: vector 0 then starts ON a line boundary, so every 1 KiB
@@ -318,17 +327,16 @@ __device__ __forceinline__ void row_setup(Row<T> &J, int lane) {
     // whose pitch is not a multiple of 128 bytes, which is the normal case).
     constexpr int LINE = 128 / (int)sizeof(T);
     J.mis = (int)((reinterpret_cast<uintptr_t>(J.drow) / sizeof(T)) & (LINE - 1));
-    J.v_first = (J.mis + VEC - 1) / VEC;
-    J.v_end = (J.n + J.mis) / VEC;
-    const int head_end = min(J.n, J.v_first * VEC - J.mis);        // pixels [0, head_end)
-    const int tail_start = max(head_end, J.v_end * VEC - J.mis);   // pixels [tail_start, n)
-    int p = -1;
-    if (lane < VEC) {
-        if (lane < head_end) p = lane;
-    } else if (lane < 2 * VEC) {
-        if (tail_start + (lane - VEC) < J.n) p = tail_start + (lane - VEC);
-    }
-    J.edge_p = p;
+    const bool seams = sizeof(T) == 2 && J.n > 0;
+    const bool head_line = seams && (seam_flags & SEAM_HAS_LEFT) && J.mis > 0;
+    const int n_own = (seams && (seam_flags & SEAM_LEAVE_TAIL)) ? J.n - ((J.n + J.mis) & (LINE - 1)) : J.n;   // n >= LINE there
+    J.v_first = head_line ? LINE / VEC : (J.mis + VEC - 1) / VEC;
+    J.v_end = (n_own + J.mis) / VEC;
+    const int head_end = head_line ? 0 : min(n_own, J.v_first * VEC - J.mis);   // pixels [0, head_end)
+    const int tail_start = max(head_end, J.v_end * VEC - J.mis);               // pixels [tail_start, n_own)
+    J.edge_p = head_line ? lane - J.mis : (lane < head_end ? lane : NO_EDGE);
+    J.tail_p = (lane < VEC && tail_start + lane < n_own) ? tail_start + lane : -1;
+    J.lzero = (seam_flags & SEAM_LEFT_ZERO) != 0;
 }
 
 // plain loads: the tile is read once, but non-temporal loads measured 3-8 % slower here
@@ -348,10 +356,22 @@ __device__ __forceinline__ void slot_load(Slot<T, FLAT> &S, const Row<T> &J, int
             for (int q = 0; q < VEC / 2; ++q) S.g64[q] = ldg<F64x2U>(reinterpret_cast<const double *>(J.frow) + p0 + 2 * q);
         }
     }
-    if (k == 0 && J.edge_p >= 0) {
-        S.edge = ldg_s<T>(J.srow + J.edge_p);
-        if (FLAT == 1 && J.frow) S.eg32 = ldg_s<float>(reinterpret_cast<const float *>(J.frow) + J.edge_p);
-        if (FLAT == 2 && J.frow) S.eg64 = ldg_s<double>(reinterpret_cast<const double *>(J.frow) + J.edge_p);
+    if (k == 0 && J.edge_p > NO_EDGE) {
+        const int p = J.edge_p;
+        const bool left = p < 0;
+        if (left && J.lzero) {
+            S.edge = 0;
+        } else {
+            S.edge = ldg_s<T>((left ? J.lsrow : J.srow) + p);
+            const char *fr = left ? J.lfrow : J.frow;
+            if (FLAT == 1 && J.frow) S.eg32 = ldg_s<float>(reinterpret_cast<const float *>(fr) + p);
+            if (FLAT == 2 && J.frow) S.eg64 = ldg_s<double>(reinterpret_cast<const double *>(fr) + p);
+        }
+    }
+    if (k == 1 && J.tail_p >= 0) {
+        S.edge = ldg_s<T>(J.srow + J.tail_p);
+        if (FLAT == 1 && J.frow) S.eg32 = ldg_s<float>(reinterpret_cast<const float *>(J.frow) + J.tail_p);
+        if (FLAT == 2 && J.frow) S.eg64 = ldg_s<double>(reinterpret_cast<const double *>(J.frow) + J.tail_p);
     }
 }
 
@@ -392,11 +412,14 @@ __device__ __forceinline__ void slot_store(Slot<T, FLAT> &S, const Row<T> &J, in
         }
         stg_nt(J.drow + (v * VEC - J.mis), px);
     }
-    if (k == 0 && J.edge_p >= 0) {
+    const bool head = k == 0 && J.edge_p > NO_EDGE, tail = k == 1 && J.tail_p >= 0;
+    if (head || tail) {
         T t = S.edge;
-        if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T, RND>(t, S.eg32) : flat_f32<T, RND>(t, S.eg32);
-        if (FLAT == 2 && J.frow) t = FAST ? flat_f64_fast<T>(t, S.eg64) : flat_f64<T>(t, S.eg64);
-        stg_s<T>(J.drow + J.edge_p, t);
+        if (!(head && J.edge_p < 0 && J.lzero)) {   // (zero fill left of the seam stays 0)
+            if (FLAT == 1 && J.frow) t = FAST ? flat_f32_fast<T, RND>(t, S.eg32) : flat_f32<T, RND>(t, S.eg32);
+            if (FLAT == 2 && J.frow) t = FAST ? flat_f64_fast<T>(t, S.eg64) : flat_f64<T>(t, S.eg64);
+        }
+        stg_s<T>(J.drow + (head ? J.edge_p : J.tail_p), t);
     }
 }
 
@@ -407,18 +430,15 @@ __device__ __forceinline__ void row_zero(T *drow, int n, int lane, bool leave_ta
     Row<T> J;
     J.drow = drow;
     J.n = n;
-    row_setup<T>(J, lane);
-    if (leave_tail) {   // the line the row ends in is written by the right neighbour (Seam in common.h; n >= one line)
-        constexpr int LINE = 128 / (int)sizeof(T);
-        J.v_end = (n - ((n + J.mis) & (LINE - 1)) + J.mis) / VEC;
-        if (lane >= VEC) J.edge_p = -1;
-    }
+    // leave_tail: the line the row ends in is written by the right neighbour (Seam in common.h; n >= one line)
+    row_setup<T>(J, lane, leave_tail ? SEAM_LEAVE_TAIL : 0);
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int v = lane + 64 * k;
         if (v >= J.v_first && v < J.v_end) stg_nt(drow + (v * VEC - J.mis), u32x4{0, 0, 0, 0});
     }
-    if (J.edge_p >= 0) stg_s<T>(drow + J.edge_p, 0);
+    if (J.edge_p > NO_EDGE) stg_s<T>(drow + J.edge_p, 0);
+    if (J.tail_p >= 0) stg_s<T>(drow + J.tail_p, 0);
 }
 
 #ifndef SQ_DEPTH_PLAIN
@@ -457,11 +477,28 @@ __device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
 #ifndef SQ_WAVES_F64
 #define SQ_WAVES_F64 1
 #endif
+// one edge pixel through the plane's flatfield divide (the slot pipeline's arithmetic, one pixel at a time)
+template <typename T, int FLAT, int RND>
+__device__ __forceinline__ T correct_edge(T t, const char *gain, bool fast) {
+    if (FLAT == 1 && gain) {
+        const float g = ldg_s<float>(gain);
+        return fast ? flat_f32_fast<T, RND>(t, g) : flat_f32<T, RND>(t, g);
+    }
+    if (FLAT == 2 && gain) {
+        const double g = ldg_s<double>(gain);
+        return fast ? flat_f64_fast<T>(t, g) : flat_f64<T>(t, g);
+    }
+    return t;
+}
+
+// seam: who writes the cache line at this item's left / right end (Seam in common.h; uint16 only -- a kernel honours the
+// records for every item of a plane or for none); ltile: the plane's tile left of the seam
 template <typename T, int FLAT, int RND = 0>
 __device__ __forceinline__ void process_item(const FuseParams &P, int plane, const Item &it, const T *tile, int wave,
-                                             int lane) {
+                                             int lane, const Seam seam = Seam{-1, 0, 0, 0}, const T *ltile = nullptr) {
     constexpr int VEC = Pix<T>::N;
     constexpr int FSZ = FLAT == 2 ? 8 : 4;
+    constexpr int LINE = 128 / (int)sizeof(T);
 #ifndef SQ_RB_FLAT
 #define SQ_RB_FLAT 1   // with gains a wave pipelines one row at a time (measured 0.8 % faster than two: less row state)
 #endif
@@ -470,15 +507,33 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
     constexpr int NSTEP = RB * SLOTS;
     constexpr int WANT = FLAT == 0 ? SQ_DEPTH_PLAIN : (FLAT == 1 ? SQ_DEPTH_F32 : SQ_DEPTH_F64);
     constexpr int DEPTH = WANT < NSTEP ? WANT : NSTEP;
+    static_assert(SLOTS >= 2, "the tail pixels ride on a row's second slot");
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    const int sflags = sizeof(T) == 2 ? seam.flags : 0;
+    const bool has_left = sflags & SEAM_HAS_LEFT, lzero = sflags & SEAM_LEFT_ZERO, leave_tail = sflags & SEAM_LEAVE_TAIL;
     T *canvas = static_cast<T *>(P.canvas) + plane * P.canvas_plane_stride;
-    if (!it.nref) {   // uncovered canvas: zeros (da.zeros, stitcher.py:362)
-        for (int r = wave; r < rows; r += 4)
-            row_zero<T>(canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x, n, lane);
-        return;
-    }
     const char *flat = (FLAT && P.flat_ptrs) ? static_cast<const char *>(P.flat_ptrs[plane]) : nullptr;
     const bool fast = FLAT != 0 && P.flat_class && (P.flat_class[plane] & 1u) == 0;
+    if (!it.nref) {   // uncovered canvas: zeros (da.zeros, stitcher.py:362)
+        for (int r = wave; r < rows; r += 4) {
+            T *d = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(d) / sizeof(T)) & (LINE - 1));
+            const int head = (has_left && mis > 0) ? mis : 0;   // pixels of the left neighbour in the seam's line
+            if (head && !lzero) {   // the seam's line: the left tile's pixels, then zeros
+                const int p = lane - mis;
+                const int po = p < 0 ? p : -1;
+                const int64_t at = (int64_t)(seam.b + r) * P.tile_pitch + seam.c + po;
+                const T e = correct_edge<T, FLAT, RND>(ldg_s<T>(ltile + at), flat ? flat + ((int64_t)(seam.b + r) * P.tile_w + seam.c + po) * FSZ : nullptr, fast);
+                stg_s<T>(d + p, p < 0 ? e : (T)0);
+                row_zero<T>(d + (LINE - head), n - (LINE - head), lane, leave_tail);    // after the seam's line
+            } else if (head) {
+                row_zero<T>(d - head, n + head, lane, leave_tail);                      // zeros from the line boundary
+            } else {
+                row_zero<T>(d, n, lane, leave_tail);
+            }
+        }
+        return;
+    }
     for (int rb = wave; rb < rows; rb += 4 * RB) {
         Row<T> J[RB];
 #pragma unroll
@@ -488,7 +543,10 @@ __device__ __forceinline__ void process_item(const FuseParams &P, int plane, con
             J[j].drow = canvas + (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
             J[j].srow = tile + (int64_t)(it.b + r) * P.tile_pitch + it.c;
             J[j].frow = flat ? flat + ((int64_t)(it.b + r) * P.tile_w + it.c) * FSZ : nullptr;
-            row_setup<T>(J[j], lane);
+            const bool lt = has_left && !lzero;
+            J[j].lsrow = lt ? ltile + (int64_t)(seam.b + r) * P.tile_pitch + seam.c : J[j].srow;
+            J[j].lfrow = (lt && flat) ? flat + ((int64_t)(seam.b + r) * P.tile_w + seam.c) * FSZ : J[j].frow;
+            row_setup<T>(J[j], lane, sflags);
         }
         if (fast) pipeline_rows<T, FLAT, true, RND, RB, SLOTS, DEPTH>(J, lane);
         else pipeline_rows<T, FLAT, false, RND, RB, SLOTS, DEPTH>(J, lane);
@@ -594,6 +652,27 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
     }
 }
 
+// what a (plane, item) of the per-plane kernel needs beside its descriptor
+struct PlaneAux {
+    const void *tile, *ltile;
+    Seam seam;
+};
+template <typename T>
+__device__ __forceinline__ PlaneAux plane_aux(const FuseParams &P, int plane, const Item &it, int64_t pos) {
+    PlaneAux A;
+    A.tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+    A.seam = (sizeof(T) == 2 && P.seams) ? P.seams[pos] : Seam{-1, 0, 0, 0};
+    A.ltile = ((A.seam.flags & SEAM_HAS_LEFT) && !(A.seam.flags & SEAM_LEFT_ZERO)) ? tile_ptr<T>(P, plane, A.seam.a) : nullptr;
+    return A;
+}
+__device__ __forceinline__ Seam sgpr(Seam s) {
+    s.a = sgpr(s.a);
+    s.b = sgpr(s.b);
+    s.c = sgpr(s.c);
+    s.flags = sgpr(s.flags);
+    return s;
+}
+
 template <typename T, int FLAT, bool DYN>
 __global__ __launch_bounds__(256, (FLAT == 1 ? (sizeof(T) == 2 ? SQ_WAVES_F32 : 1) : (FLAT == 2 ? SQ_WAVES_F64 : SQ_WAVES_PLAIN)))
 void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int64_t n_work) {
@@ -601,38 +680,39 @@ void fuse_overwrite_kernel(const FuseParams P, const int64_t n_items, const int6
     const int lane = threadIdx.x & 63;
 
     if (!DYN) {
-        // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor and tile
-        // pointer are fetched while the current item streams
+        // persistent grid-stride walk: block b takes items b, b + G, ...; the next descriptor, seam record and tile
+        // pointers are fetched while the current item streams
         int64_t work = blockIdx.x;
         if (work >= n_work) return;
         int plane = (int)(work / n_items);
         Item it = P.items[work - plane * n_items];
-        const T *tile = it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr;
+        PlaneAux A = plane_aux<T>(P, plane, it, work - plane * n_items);
         while (true) {
             const int64_t nwork = work + gridDim.x;
             const bool more = nwork < n_work;
             int nplane = plane;
             Item nit = it;
-            const T *ntile = nullptr;
+            PlaneAux nA = A;
             if (more) {
                 nplane = (int)(nwork / n_items);
                 nit = P.items[nwork - nplane * n_items];
-                ntile = nit.nref ? tile_ptr<T>(P, nplane, nit.a) : nullptr;
+                nA = plane_aux<T>(P, nplane, nit, nwork - nplane * n_items);
             }
-            process_item<T, FLAT>(P, plane, it, tile, wave, lane);
+            process_item<T, FLAT>(P, plane, it, static_cast<const T *>(A.tile), wave, lane, A.seam, static_cast<const T *>(A.ltile));
             if (!more) break;
             work = nwork;
             plane = nplane;
             it = nit;
-            tile = ntile;
+            A = nA;
         }
         return;
     }
-    for_each_queued_item<const void *>(
+    for_each_queued_item<PlaneAux>(
         P, n_items, (uint32_t)P.n_planes,
-        [&](int plane, const Item &it, int64_t) -> const void * { return it.nref ? tile_ptr<T>(P, plane, it.a) : nullptr; },
-        [&](int plane, const Item &it, const void *const &tile) {
-            process_item<T, FLAT>(P, plane, it, sgpr(static_cast<const T *>(tile)), wave, lane);
+        [&](int plane, const Item &it, int64_t pos) -> PlaneAux { return plane_aux<T>(P, plane, it, pos); },
+        [&](int plane, const Item &it, const PlaneAux &A) {
+            process_item<T, FLAT>(P, plane, it, sgpr(static_cast<const T *>(A.tile)), wave, lane, sgpr(A.seam),
+                                  sgpr(static_cast<const T *>(A.ltile)));
         });
 }
 
@@ -900,8 +980,9 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
     };
     auto body = [&](int, const Item &it, const UnitAux &A) {
         const int gn = sgpr(A.g.n);
-        if (gn == 1) {   // (a group of one through process_item_zg, seam owners included, measured the same: 0.514 / 0.514)
-            process_item<T, FLAT>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane);
+        if (gn == 1) {   // the per-plane pipeline (a group of one through process_item_zg measured the same)
+            process_item<T, FLAT>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane, sgpr(A.seam),
+                                  sgpr(static_cast<const T *>(A.ltile[0])));
         } else if (gn == ZB) {
             process_item_zg<true, 0, G>(P, A, gn, it, wave, lane);
         } else {

@@ -477,11 +477,12 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('gdtype', [np.float32, np.float64], ids=['f32', 'f64'])
+@pytest.mark.parametrize('gdtype', [np.float32, np.float64, None], ids=['f32', 'f64', 'nogain'])
 @pytest.mark.parametrize('queues', [False, True], ids=['static', 'queues'])
 @pytest.mark.parametrize('seed', range(5))
 def test_seam_lines_have_one_writer(seed, queues, gdtype):
-    """Plane groups, tiles at least a cache line wide either side of every vertical seam: the item right of a seam writes
+    """Tiles at least a cache line wide either side of every vertical seam -- through the plane-group kernel, through the
+    per-plane pipeline with the same gains (odd seeds: SQ_FUSE_NO_PLANE_GROUPS) and without gains: the item right of a seam writes
     the whole 128-byte line the seam falls in (pixels of BOTH tiles, or zero fill on the left), the item left of it stops
     at the line boundary (Seam in csrc/common.h).  Canvas pitches that put every row at a different phase, pitches that
     are multiples of a line, a base address off the line grid: every plane equals the oracle, and the canvas padding
@@ -504,17 +505,19 @@ def test_seam_lines_have_one_writer(seed, queues, gdtype):
     cw = int((rects[:, 5] + rects[:, 3]).max()) + int(rng.integers(0, 140))
     planes = int(rng.integers(2, 8))
     tiles = rng.integers(0, 65536, size=(planes, len(rects), th, tw)).astype(np.uint16)
-    gain = np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(gdtype)
-    d_gain = torch.from_numpy(gain).to(dev)
+    gain = None if gdtype is None else np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(gdtype)
+    d_gain = None if gain is None else torch.from_numpy(gain).to(dev)
     d_tiles = torch.from_numpy(tiles).to(dev)
     plan = native.FusePlan(rects, th, tw, ch, cw)
     flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    if seed % 2:
+        flags |= native.SQ_FUSE_NO_PLANE_GROUPS        # the per-plane pipeline honours the seam records too
     want = [O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, gain) for p in range(planes)]
     for pitch, lead in ((cw, 0), (cw + 1, 0), (-(-cw // 64) * 64, 0), (cw + 37, 64 * 3), (cw + 2, 64 * 5 + 13)):
         stride = -(-(ch * pitch) // 64) * 64                 # planes a multiple of 128 bytes apart: groups form
         buf = torch.full((lead + planes * stride + 64,), 0x5A5A, dtype=torch.uint16, device=dev)
         canvas = buf[lead:].as_strided((planes, ch, cw), (stride, pitch, 1))
-        native.fuse_planes(plan, d_tiles, canvas, [d_gain] * planes, flags=flags)
+        native.fuse_planes(plan, d_tiles, canvas, None if d_gain is None else [d_gain] * planes, flags=flags)
         torch.cuda.synchronize()
         host = buf.cpu().numpy()
         for p in range(planes):
