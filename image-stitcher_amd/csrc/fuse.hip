@@ -1575,6 +1575,8 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
     const int plane = blockIdx.y;
     const G *f = static_cast<const G *>(flat_ptrs[plane]);
     if (!f) return;
+    for (int q = 0; q < plane; ++q)          // the z planes of a channel name the same image: read it once
+        if (flat_ptrs[q] == f) return;       // (flat_class_share_kernel hands the class on)
     const G lo = (G)__builtin_ldexp(1.0, FAST_MIN_EXP), hi = (G)__builtin_ldexp(1.0, FAST_END_EXP);
     const G mlo = (G)__builtin_ldexp(1.0, -MODERATE_EXP), mhi = (G)__builtin_ldexp(1.0, MODERATE_EXP);
     bool odd = false, wide = false;
@@ -1587,6 +1589,19 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
     }
     const uint32_t bits = (__builtin_amdgcn_ballot_w64(odd) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(wide) ? 2u : 0u);
     if (bits && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], bits);
+}
+
+// after the pre-pass: planes that share a gain image share its class
+__global__ __launch_bounds__(256) void flat_class_share_kernel(const void *const *flat_ptrs, int n_planes, uint32_t *cls) {
+    for (int p = threadIdx.x; p < n_planes; p += 256) {
+        const void *f = flat_ptrs[p];
+        if (!f) continue;
+        for (int q = 0; q < p; ++q)
+            if (flat_ptrs[q] == f) {
+                cls[p] = cls[q];     // q is the first plane with this image: the one the pre-pass read (never written here)
+                break;
+            }
+    }
 }
 
 // exhaustive check of the fast divide against the IEEE path: final clipped integers, one binade of
@@ -1807,6 +1822,9 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             else
                 hipLaunchKernelGGL(flat_classify_kernel<double>, dim3(64, a->n_planes), dim3(256), 0, stream, a->flat_ptrs_dev,
                                    (int64_t)a->tile_h * a->tile_w, static_cast<uint32_t *>(a->scratch_dev));
+            if (a->n_planes > 1)
+                hipLaunchKernelGGL(flat_class_share_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, a->n_planes,
+                                   static_cast<uint32_t *>(a->scratch_dev));
             P.flat_class = static_cast<const uint32_t *>(a->scratch_dev);
         }
         // the queues count in 32 bits; a launch with fewer than ~64 items per resident workgroup is over
