@@ -360,23 +360,28 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             std::vector<int32_t> at(first.begin(), first.end() - 1);
             for (size_t i = 0; i < items.size(); ++i) by_band[at[items[i].dst_y / BLOCK_ROWS]++] = (int32_t)i;
         }
+        // inside a band: by (first row, END column), so that the item ending where J begins is a binary search away
+        // (a 100 x 100 grid has 100+ items per band and millions of items)
+        auto end_key = [&](int32_t i) { return ((int64_t)items[i].dst_y << 32) | (uint32_t)(items[i].dst_x + (items[i].hw & 0xFFFF)); };
+        for (int k = 0; k < nb; ++k)
+            std::sort(by_band.begin() + first[k], by_band.begin() + first[k + 1],
+                      [&](int32_t a, int32_t b) { return end_key(a) < end_key(b); });
         for (size_t j = 0; j < items.size(); ++j) {
             const Item &J = items[j];
             if ((J.hw & 0xFFFF) < SEAM_MIN_COLS || J.dst_x == 0) continue;
             const int k = J.dst_y / BLOCK_ROWS;
-            for (int32_t q = first[k]; q < first[k + 1]; ++q) {
-                const Item &I = items[by_band[q]];
-                const int in = I.hw & 0xFFFF;
-                if (I.dst_x + in != J.dst_x || I.dst_y != J.dst_y || (I.hw >> 16) != (J.hw >> 16)) continue;
-                if (in >= SEAM_MIN_COLS) {
-                    seams[j].a = I.a;
-                    seams[j].b = I.b;
-                    seams[j].c = I.c + in;
-                    seams[j].flags |= SEAM_HAS_LEFT | (I.nref ? 0 : SEAM_LEFT_ZERO);
-                    seams[by_band[q]].flags |= SEAM_LEAVE_TAIL;
-                }
-                break;
-            }
+            const int64_t want = ((int64_t)J.dst_y << 32) | (uint32_t)J.dst_x;
+            auto lo = std::lower_bound(by_band.begin() + first[k], by_band.begin() + first[k + 1], want,
+                                       [&](int32_t a, int64_t key) { return end_key(a) < key; });
+            if (lo == by_band.begin() + first[k + 1] || end_key(*lo) != want) continue;
+            const Item &I = items[*lo];      // the canvas is partitioned: at most one item ends at (row, column)
+            const int in = I.hw & 0xFFFF;
+            if ((I.hw >> 16) != (J.hw >> 16) || in < SEAM_MIN_COLS) continue;
+            seams[j].a = I.a;
+            seams[j].b = I.b;
+            seams[j].c = I.c + in;
+            seams[j].flags |= SEAM_HAS_LEFT | (I.nref ? 0 : SEAM_LEFT_ZERO);
+            seams[*lo].flags |= SEAM_LEAVE_TAIL;
         }
     }
 
