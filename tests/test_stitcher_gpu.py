@@ -280,3 +280,35 @@ def test_cli_with_ff_estimates_gains_on_the_device_and_says_so(tmp_path, capsys)
     want = O.stitch_region(acq, 0, 'R0', read_image, True, shifts, st.flatfields, True)
     store = os.path.join(st.output_folder, '0_stitched', 'R0_stitched.ome.zarr')
     np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), want)
+
+
+@pytest.mark.parametrize('layout', ['strips_ifd_last', 'big_endian'])
+def test_tile_files_in_other_tiff_layouts(tmp_path, layout):
+    """The tile files of a golden acquisition rewritten the way libtiff lays them out (8-row strips, IFD after the pixel
+    data: read straight into the staging buffer by ``tiffio.read_image_into``) and big-endian (declined there, decoded by
+    ``read_image``): the same canvas as the reference's, voxel for voxel."""
+    from test_host_cpu import _strip_tiff
+    from image_stitcher_amd import tiffio
+    info, arrays = load_case('reg_3x4_small')
+    spec = spec_of(info)
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    n = 0
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(('.tiff', '.tif')):
+                p = os.path.join(dp, f)
+                img = tiffio.read_image(p)
+                with open(p, 'wb') as fh:
+                    fh.write(_strip_tiff(img, 8, big_endian=(layout == 'big_endian')))
+                probe = np.zeros_like(img)
+                assert tiffio.read_image_into(p, probe) == (layout != 'big_endian')
+                n += 1
+    assert n >= 12
+    st = _prepared(info, root, normalization=None)
+    st.calculate_shifts(st.timepoints[0], st.regions[0])
+    assert list(st.h_shift) == info['h_shift'] and list(st.v_shift) == info['v_shift']
+    key, cinfo = next(iter(info['canvases'].items()))
+    t, region = key[1:].split('_', 1)
+    canvas = st.stitch_region(int(t), region)
+    assert sha(canvas) == cinfo['sha256']
