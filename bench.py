@@ -175,14 +175,15 @@ def algorithmic_bytes(n_planes, covered, hc, wc, flat):
 def committed_traffic(workload, n_planes):
     """PMC counters need their own rocprofv3 passes (the guide's HBM section: separate --pmc runs); the bench line
     carries the last committed measurement of this exact launch, and says so."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')) as fh:
-            pm = json.load(fh)
-        if pm.get('workload') == workload and pm.get('planes') == n_planes:
-            return pm['traffic_bytes_per_launch'], 'profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of ' \
-                'this launch on another box; not measured in this run)'
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ('pmc_traffic_latest.json', 'pmc_traffic_cfg4_batch.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                pm = json.load(fh)
+            if pm.get('workload') == workload and pm.get('planes') == n_planes:
+                return pm['traffic_bytes_per_launch'], f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of ' \
+                    'this launch on another box; not measured in this run)'
+        except (OSError, ValueError, KeyError):
+            pass
     return None, 'not measured (no committed PMC pass for this workload / plane count)'
 
 
@@ -580,8 +581,9 @@ def run_job(ctx):
                            'resident batch one fusion launch; a batch\'s tiles are synthesised on the device before its timed '
                            'segment (inputs resident when timing starts); timed = MAX over ranks of the summed segments'},
         'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_zg_kernel (u16, f32 gains, plane groups)', 'achieved': round(achieved, 1),
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                     'traffic_source': 'not measured (no PMC pass for this workload)',
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                     'traffic': committed_traffic(wl['name'], int(round(float(npl.mean()))))[0],
+                     'traffic_source': committed_traffic(wl['name'], int(round(float(npl.mean()))))[1],
                      'algorithmic_bytes_per_launch': int(alg * npl.mean()), 'launch_ms': round(float(ms.mean()), 4),
                      'frac_per_rank': [round(f, 4) for f in fracs], 'of_rank': 0},
         'parity': shift_parity(shifts, truth),

@@ -26,11 +26,13 @@ def main():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ab', type=int, default=None, help='also time these flags, alternating with --flags in the same process (same buffers)')
     ap.add_argument('--libs', default=None, help='comma-separated build variants (tools/build_variant.sh names, or "default") timed alternately in this process on the same buffers')
+    ap.add_argument('--u8', action='store_true', help='uint8 tiles and canvas')
     ap.add_argument('--feather', action='store_true', help='feather plan (uncropped rectangles, blended overlaps)')
     ap.add_argument('--canvas-first', action='store_true', help='allocate the canvas before the tiles')
     ap.add_argument('--blocks', type=int, default=0, help='cap / set the launch grid (grid_blocks); with --flags 2 and a huge value: one workgroup per work unit')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
+    TDT, NDT, ESZ = (torch.uint8, 'uint8', 1) if a.u8 else (torch.uint16, 'uint16', 2)
     g, T = a.grid, a.tile
     shifts = placement.Shifts((a.drift[0], -a.ov), (-a.ov, a.drift[1]))
     rects = placement.grid_rects(g, g, T, T, shifts, crop=not a.feather)
@@ -41,19 +43,19 @@ def main():
     print(f'plan: {plan.n_spans} spans, {plan.n_items} items, table {plan.table.nbytes/1e6:.2f} MB, '
           f'{time.time()-t0:.3f}s; canvas {hc}x{wc}; covered {plan.covered_voxels/(hc*wc):.3f}')
     spec = synth.GridSpec(rows=g, cols=g, tile_h=T, tile_w=T, ov_y=a.ov, ov_x=a.ov, seed=1)
-    early = (native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else
-             torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev)) if a.canvas_first else None
-    tiles = torch.empty((a.planes, g * g, T, T), dtype=torch.uint16, device=dev)
+    early = (native.empty_canvas(a.planes, hc, wc, TDT, dev) if not a.dense else
+             torch.empty((a.planes, hc, wc), dtype=TDT, device=dev)) if a.canvas_first else None
+    tiles = torch.empty((a.planes, g * g, T, T), dtype=TDT, device=dev)
     for p in range(a.planes):
         desc = np.zeros(g * g, dtype=native.SYNTH_DTYPE)
         for r in range(g):
             for c in range(g):
                 oy, ox = spec.origin(r, c)
                 desc[r * g + c] = (spec.scene_seed(0, 0, p, 0) % 2**64, spec.noise_seed(0, 0, p, 0, r * g + c) % 2**64, oy, ox)
-        native.synth_tiles(desc, T, T, 200, 'uint16', dev, out=tiles[p])
+        native.synth_tiles(desc, T, T, 200 if not a.u8 else 2, NDT, dev, out=tiles[p])
     torch.cuda.synchronize()
-    canvas = early if early is not None else (native.empty_canvas(a.planes, hc, wc, torch.uint16, dev) if not a.dense else
-                                              torch.empty((a.planes, hc, wc), dtype=torch.uint16, device=dev))
+    canvas = early if early is not None else (native.empty_canvas(a.planes, hc, wc, TDT, dev) if not a.dense else
+                                              torch.empty((a.planes, hc, wc), dtype=TDT, device=dev))
     print(f'tiles at {tiles.data_ptr():#x}, canvas at {canvas.data_ptr():#x}')
     flats = None
     if a.flat != 'none':
@@ -73,7 +75,7 @@ def main():
     torch.cuda.synchronize()
     ms = np.array([e0.elapsed_time(e1) for e0, e1 in evs])
     vox = a.planes * hc * wc
-    alg = a.planes * (plan.covered_voxels * 4 + (hc * wc - plan.covered_voxels) * 2)
+    alg = a.planes * (plan.covered_voxels * 2 * ESZ + (hc * wc - plan.covered_voxels) * ESZ)
     if a.feather:   # every tile pixel read once + the voxel written
         alg = a.planes * (a.grid * a.grid * T * T * 2 + hc * wc * 2)
     if a.check:

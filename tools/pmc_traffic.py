@@ -1,6 +1,6 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_traffic_latest.json.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg3 40 "<note>"
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write cfg3 40 "<note>" [out.json]
 """
 import csv, glob, json, sys
 
@@ -17,5 +17,5 @@ out = dict(workload=workload, planes=planes, FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk,
            traffic_bytes_per_launch=(2 * fk + wk) * 1024,
            formula='(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 reports half the bytes of wide coalesced reads '
                    '(MI355X_MICROARCH.md, HBM); Infinity-Cache hits are counted', note=note)
-json.dump(out, open('profiles/pmc_traffic_latest.json', 'w'), indent=1)
+json.dump(out, open(sys.argv[6] if len(sys.argv) > 6 else 'profiles/pmc_traffic_latest.json', 'w'), indent=1)
 print(json.dumps(out))
