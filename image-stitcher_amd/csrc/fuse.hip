@@ -435,6 +435,7 @@ __device__ __forceinline__ void row_zero(T *drow, int n, int lane, bool leave_ta
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int v = lane + 64 * k;
+        // (plain instead of non-temporal stores for the zeros: 0.634 against 0.642 for the whole launch)
         if (v >= J.v_first && v < J.v_end) stg_nt(drow + (v * VEC - J.mis), u32x4{0, 0, 0, 0});
     }
     if (J.edge_p > NO_EDGE) stg_s<T>(drow + J.edge_p, 0);
