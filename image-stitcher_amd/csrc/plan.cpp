@@ -387,10 +387,13 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 
     auto key_of = [&](const Item &it) {
         if (bands) return std::min(it.dst_y / BLOCK_ROWS, nblk - 2);
+        // (experiment builds, SQ_PLAN_ORDER=5: the zero-fill items dealt into the lanes by their canvas row block instead
+        // of following them -- fills running beside copies instead of after them)
+        if (order_mode == 5 && !it.nref) return (it.dst_y / BLOCK_ROWS) % (nblk - 1);
         return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1;
     };
     std::vector<int64_t> count(nblk, 0);
-    for (const Item &it : items) ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4) ? key_of(it) : 0];
+    for (const Item &it : items) ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4 || order_mode == 5) ? key_of(it) : 0];
     const auto t_items = std::chrono::steady_clock::now();
 
     auto *plan = new sq_fuse_plan;
@@ -456,7 +459,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             tail_at[x] = tail;
             tail += lane_len[x] - common;
         }
-        if (order_mode == 2 || order_mode == 4) {   // the header is already in the table: patch the field
+        if (order_mode == 2 || order_mode == 4 || order_mode == 5) {   // the header is already in the table: patch the field
             hd.lane_items = common;
             std::memcpy(plan->table.ptr, &hd, sizeof hd);
         }
