@@ -2,6 +2,7 @@
 """Bench of the registration-and-fusion hot path on MI355X (contract: see the task brief).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,7 +14,8 @@ plan, then ONE fusion launch over all 40 planes.
 
 N > 1 (default workload ``cfg4`` = BASELINE.json configs[3], the configuration the metric is quoted on): the
 32x32 grid of 2048x2048 tiles, 4 channels x 50 z = 200 (c, z) planes = 1.6 TiB of tiles, ``-r -ff``.  STRONG
-scaling: the 200 planes are dealt block-cyclically over the N ranks (plane p -> rank p % N), no image data is
+scaling: every rank takes ONE contiguous run of the 200 planes (sharding.contiguous_blocks: a channel's z planes
+stay together and go through the kernel in full groups), no image data is
 exchanged; rank 0 registers the centre pairs and the shift row is all-gathered over RCCL once per step.  A rank
 walks its planes in HBM-resident batches (tiles + canvases of a batch fill the card); a batch's tiles are
 synthesised on the device BEFORE that batch's timed segment starts (inputs resident when timing starts, as the
@@ -70,6 +72,9 @@ def main():
                     help='default: cfg3 on one GPU, cfg4 (the headline job, strong scaling) on several')
     ap.add_argument('--planes', type=int, default=0, help='override the number of (c,z) planes (resident planes / job size)')
     ap.add_argument('--batch', type=int, default=0, help='cfg4: planes per resident batch (default: what fits, at most 10, a multiple of 5)')
+    ap.add_argument('--centre-pairs', action='store_true',
+                    help="cfg4: register like the reference (the centre tile's two pairs, on rank 0; stitcher.py:455-485) instead of "
+                         'ALL 1 984 adjacent pairs sharded over the ranks (the default: the north star\'s registration)')
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
@@ -79,6 +84,11 @@ def main():
                     help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else the committed measurement)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (torch is not
+        # even imported yet) and never will: the N ranks are children, their rank 0 prints the JSON line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     from image_stitcher_amd import sharding
@@ -87,7 +97,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     local_dev = local_rank % torch.cuda.device_count()
@@ -121,6 +131,38 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks (one process per GPU)
+# ------------------------------------------------------------------------------------------------------------
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_argv(n, bench_args, port):
+    """The command line of the N-rank run: torch.distributed.run on this one node, rendezvous on 127.0.0.1 (the
+    container's host name may not resolve), this script with the caller's own arguments."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(bench_args)
+
+
+def launch_ranks(n, bench_args):
+    """Start the ranks as CHILD processes and return their exit status (non-zero if any rank failed; nothing is
+    restarted).  stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs across processes on these hosts
+    env.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.Popen(launch_argv(n, bench_args, free_port()), env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait() or 130
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -333,7 +375,10 @@ def run_region(ctx):
     out = {
         'metric': 'stitched Mvoxels/s', 'value': round(value, 1), 'unit': 'Mvoxel/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        # N = 1: the single-GPU point of the strong-scaling curve the N > 1 runs draw (a fixed job divided over the
+        # GPUs); --weak with N > 1: one region per rank
+        'scaling': 'weak' if (world > 1 and args.weak) else 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'config': {'workload': wl['desc'], 'planes_resident_per_gpu': n_planes,
                    'canvas': [hc, wc], 'tiles_per_plane': g * g,
@@ -400,9 +445,17 @@ def cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas
     up to ``max_planes`` (c, z) planes, ~10-30 s of single-core work.  Geometry, shifts and voxels all come
     from oracle code; the GPU canvas is compared with the result voxel by voxel."""
     from oracle import stitch_oracle as O
-    n = min(max_planes, tiles.shape[0])
-    host = tiles[:n].cpu().numpy()
-    flats = [flat_list[p].cpu().numpy() if flat_list else None for p in range(n)]
+    total = tiles.shape[0]
+    n = min(max_planes, total)
+    # the sample is spread over the launch: with 4 channels x 10 z and 16 planes, z 0-3 of EVERY channel (each channel
+    # has its own gain image), not the first 16 planes
+    n_groups = len({id(f) for f in flat_list}) if flat_list else 1
+    per = max(1, total // n_groups)
+    take = -(-n // n_groups)
+    sample = sorted({gi * per + k for gi in range(n_groups) for k in range(min(take, per))})[:n] if n < total else list(range(total))
+    n = len(sample)
+    host = tiles[sample].cpu().numpy()
+    flats = [flat_list[p].cpu().numpy() if flat_list else None for p in sample]
     t0 = time.perf_counter()
     mx, my = O.max_overlaps(xs, ys, TILE, TILE, spec.pixel_size_um, spec.pixel_binning)
     ci = ri = (g - 1) // 2
@@ -415,8 +468,8 @@ def cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas
     voxels = 0
     dt_check = 0.0
     mismatched = 0
-    for p in range(n):
-        plane = O.fuse_plane_overwrite([host[p, i] for i in order], rects, hc, wc, flats[p])
+    for k, p in enumerate(sample):
+        plane = O.fuse_plane_overwrite([host[k, i] for i in order], rects, hc, wc, flats[k])
         voxels += plane.size
         tc = time.perf_counter()   # the comparison with the GPU canvas is not part of the CPU timing
         mismatched += int(np.count_nonzero(canvas[p].cpu().numpy() != plane))
@@ -427,8 +480,8 @@ def cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas
             'sample': f'{n} (c,z) planes of the workload ({g}x{g} tiles -> {hc}x{wc} canvas each): registration of '
                       f'the 2 centre pairs once + fusion, numpy oracle, {dt:.1f} s, 1 of {os.cpu_count()} host cores used'}
     check = {'fused_max_rel_err': 0.0 if mismatched == 0 else None, 'fused_mismatched_voxels': mismatched,
-             'fused_checked': f'{n} of the timed launch\'s canvas planes compared voxel by voxel with the oracle '
-                              '(shifts, canvas size and rectangles from the oracle\'s own geometry)'}
+             'fused_checked': f'{n} of the timed launch\'s canvas planes (planes {sample}: every channel / gain image) compared voxel '
+                              'by voxel with the oracle (shifts, canvas size and rectangles from the oracle\'s own geometry)'}
     return base, check
 
 
@@ -465,13 +518,25 @@ def run_job(ctx):
     ptrs_all = (tiles.data_ptr() + (torch.arange(bmax, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
     ptrs_all = ptrs_all.reshape(-1).to(dev)
     flat_tables = [native.pointer_table([ffs[p // Z] for p in b], dev) for b in batches]
-    # rank 0 holds the three tiles the reference registers on (centre, right, below; channel 0, z 0: stitcher.py:455-485)
+    # Registration inputs, resident before the timed region like every other input.
+    #   default: ALL adjacent pairs of the registration plane (channel 0, z 0), dealt over the ranks in contiguous runs
+    #            of the tile-row-ordered pair list (registration.pairs_of_rank); a rank holds only the tiles ITS pairs
+    #            touch (its band of tile rows + the row below);
+    #   --centre-pairs: the reference's scheme, the centre tile and its right / lower neighbour on rank 0
+    #            (stitcher.py:455-485).
+    all_pairs = not args.centre_pairs
     ci = ri = (g - 1) // 2
-    reg_cells = [(ri, ci), (ri, ci + 1), (ri + 1, ci)]
-    reg_tiles = None
-    if rank == 0:
-        d0 = plane_desc(spec, g, 0, 0)
-        reg_tiles = native.synth_tiles(d0[[r * g + c for r, c in reg_cells]], TILE, TILE, spec.noise, 'uint16', dev)
+    d0 = plane_desc(spec, g, 0, 0)
+    mx, my = placement.registration_crop_widths(xs, ys, TILE, TILE, spec.pixel_size_um, spec.pixel_binning)
+    if all_pairs:
+        pairs = registration.grid_pair_list(g, g)
+        my_pairs = registration.pairs_of_rank(len(pairs), rank, world)
+        reg_cells = registration.cells_of_pairs(pairs, my_pairs)
+    else:
+        pairs, my_pairs = [], []
+        reg_cells = [(ri, ci), (ri, ci + 1), (ri + 1, ci)] if rank == 0 else []
+    reg_tiles = native.synth_tiles(d0[[r * g + c for r, c in reg_cells]], TILE, TILE, spec.noise, 'uint16', dev) \
+        if reg_cells else None
     reg_index = {rc: i for i, rc in enumerate(reg_cells)}
     torch.cuda.synchronize()
 
@@ -480,7 +545,8 @@ def run_job(ctx):
 
     def plan_for(shifts):
         """Host geometry + span plan, kept across steps while the shifts do not change (the plan depends on
-        nothing else); one upload per plan."""
+        nothing else); one upload per plan.  The cache is emptied after the warm-up, so the FIRST timed job builds
+        and uploads its plan inside its timed seconds, as a real run does once."""
         rects = placement.grid_rects(g, g, TILE, TILE, shifts, order=order_rc)
         key = rects.tobytes()
         if key not in plans:
@@ -489,6 +555,7 @@ def run_job(ctx):
                 raise RuntimeError(f"registration returned {shifts}, canvas {h_px}x{w_px} != planned {hc}x{wc}")
             plans.clear()
             plans[key] = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE)
+            plans[key].device_table(dev)          # the upload belongs to the job that needed the plan
         return plans[key]
 
     multi = world > 1 or dist.is_initialized()
@@ -499,11 +566,16 @@ def run_job(ctx):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def job(record):
-        """One pass over the 200 planes.  Returns this rank's timed seconds."""
-        timed = 0.0
-        sync_all()
+    def register():
+        """-> (Shifts, seconds of registration, seconds of the collective)."""
         t0 = time.perf_counter()
+        if all_pairs:
+            local = registration.register_pair_subset(reg_tiles, reg_index, pairs, my_pairs, TILE, TILE, mx, my, 'phase')
+            t1 = time.perf_counter()
+            table = sharding.all_gather_pair_table(local, len(pairs), rank, world, device=coll_dev)      # RCCL
+            t2 = time.perf_counter()
+            state['pair_table'] = table
+            return registration.shifts_from_pair_table(pairs, table, TILE, TILE, mx, my, g), t1 - t0, t2 - t1
         row = sharding.shifts_to_row(None)
         if rank == 0:    # the reference registers once, on the first region's centre tiles (stitcher.py:1244-1246)
             sh = registration.register_grid_center(reg_tiles, g, g, xs, ys, spec.pixel_size_um, spec.pixel_binning,
@@ -511,47 +583,66 @@ def run_job(ctx):
             row = sharding.shifts_to_row(sh)
         t1 = time.perf_counter()
         shifts = sharding.first_valid(sharding.all_gather_shift_table(row[None], device=coll_dev))   # RCCL
+        return shifts, t1 - t0, time.perf_counter() - t1
+
+    def synth_batch(b):
+        for k, p in enumerate(b):      # this batch's tiles -> HBM (not timed: inputs are resident when timing starts)
+            native.synth_tiles(descs[p], TILE, TILE, spec.noise, 'uint16', dev, out=tiles[k])
+
+    def job(record):
+        """One pass over the 200 planes.  Returns this rank's timed seconds = the host-clocked head (registration,
+        all-gather, geometry + plan [+ its upload when it is new], closed by a synchronisation) + the fusion launches,
+        each clocked by a pair of events on the launch stream.  The generator runs of the next batch are enqueued
+        on the same stream between the launches (after the closing event of one, before the opening event of the
+        next), so there is ONE host synchronisation per job, not two per batch."""
+        if batches:
+            synth_batch(batches[0])
+        sync_all()
+        t0 = time.perf_counter()
+        shifts, t_reg, t_gather = register()
         t2 = time.perf_counter()
         plan = plan_for(shifts)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        timed += t3 - t0
-        for k, v in (('register', t1 - t0), ('allgather', t2 - t1), ('plan', t3 - t2)):
+        for k, v in (('register', t_reg), ('allgather', t_gather), ('plan', t3 - t2)):
             lap.setdefault(k, []).append(v)
+        events = []
         for bi, b in enumerate(batches):
-            for k, p in enumerate(b):      # this batch's tiles -> HBM (not timed: inputs are resident when timing starts)
-                native.synth_tiles(descs[p], TILE, TILE, spec.noise, 'uint16', dev, out=tiles[k])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            if bi:
+                synth_batch(b)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             native.fuse_planes(plan, None, canvas[:len(b)], [ffs[p // Z] for p in b], tile_ptrs=ptrs_all[:len(b) * g * g],
                                flat_ptrs=flat_tables[bi])
             e1.record()
-            torch.cuda.synchronize()
-            timed += time.perf_counter() - t0
-            if record:
-                fuse_events.append((e0, e1, len(b)))
+            events.append((e0, e1, len(b)))
             if args.sha_out and record == 'last':
                 for k, p in enumerate(b):
                     state.setdefault('sha', {})[int(p)] = plane_digest(canvas[k])
+        torch.cuda.synchronize()
+        timed = (t3 - t0) + sum(a.elapsed_time(c) for a, c, _ in events) * 1e-3
+        if record:
+            fuse_events.extend(events)
         state['plan'], state['shifts'] = plan, shifts
         return timed
 
     for _ in range(args.warmup):
         job(False)
-    seconds = 0.0
-    for k in range(args.steps):
-        seconds += job('last' if k + 1 == args.steps else True)
+    plans.clear()          # the first timed job plans and uploads like the first job of a real run
+    per_job = [job('last' if k + 1 == args.steps else True) for k in range(args.steps)]
+    seconds = float(sum(per_job))
     sync_all()
     if args.sha_out:
         with open(f'{args.sha_out}.rank{rank}', 'w') as fh:
             json.dump(state.get('sha', {}), fh)
     mine_s = seconds
-    if multi:
-        t = torch.tensor([seconds], dtype=torch.float64, device=coll_dev or 'cpu')
+    first_job = per_job[0]
+    steady = float(np.mean(per_job[1:])) if len(per_job) > 1 else None
+    if multi:      # the job's time is the slowest rank's: MAX over ranks of the sum and of the first job
+        t = torch.tensor([seconds, first_job, steady if steady is not None else 0.0], dtype=torch.float64, device=coll_dev or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seconds = float(t.item())
+        seconds, first_job = float(t[0].item()), float(t[1].item())
+        steady = float(t[2].item()) if steady is not None else None
 
     plan, shifts = state['plan'], state['shifts']
     assert tuple(shifts.h_shift) == truth.h_shift and tuple(shifts.v_shift) == truth.v_shift, \
@@ -572,14 +663,23 @@ def run_job(ctx):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(seconds / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
+        'first_job_ms': round(first_job * 1e3, 3), 'steady_job_ms': None if steady is None else round(steady * 1e3, 3),
+        'first_job_note': 'the first timed job builds and uploads the fusion plan (cache emptied after the warm-up); the later ones '
+                          're-use it while the shifts stay; ms_per_step is the mean over ALL timed jobs, the first included',
+        'host_ms_per_job_rank0': {k: round(float(np.mean(v[args.warmup:])) * 1e3, 3) for k, v in lap.items()},
         'config': {'workload': wl['desc'], 'planes_total': total_planes, 'planes_per_gpu': len(mine),
+                   'registration': (f'all {len(pairs)} adjacent pairs of the registration plane, dealt over the ranks in contiguous runs '
+                                    f'({len(my_pairs)} pairs / {len(reg_cells)} resident tiles on rank 0), [n_pairs, 3] float64 table '
+                                    'all-gathered, per-axis median') if all_pairs else
+                                   "the reference's centre pairs on rank 0 (stitcher.py:455-485), 8-int32 row all-gathered",
                    'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g,
                    'parallelism': f'planes dealt over {world} GPUs in contiguous runs (a channel\'s z planes stay together), rank 0 registers, '
                                   f'shift row all-gathered over {"RCCL" if ctx["backend"] == "nccl" else ctx["backend"]}, no image data exchanged',
                    'shifts': {'h': list(shifts.h_shift), 'v': list(shifts.v_shift)},
-                   'step': 'the whole job: centre-pair PCC on rank 0 + all-gather + span plan (kept while the shifts stay), then per '
-                           'resident batch one fusion launch; a batch\'s tiles are synthesised on the device before its timed '
-                           'segment (inputs resident when timing starts); timed = MAX over ranks of the summed segments'},
+                   'step': 'the whole job: registration + all-gather + span plan (kept while the shifts stay), then per '
+                           'resident batch one fusion launch; a batch\'s tiles are synthesised on the device before its launch, '
+                           'outside its event pair (inputs resident when timing starts); timed = MAX over ranks of host-clocked '
+                           'head + event-clocked launches'},
         'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_zg_kernel (u16, f32 gains, plane groups)', 'achieved': round(achieved, 1),
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                      'traffic': committed_traffic(wl['name'], int(round(float(npl.mean()))))[0],

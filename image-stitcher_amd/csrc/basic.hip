@@ -8,13 +8,13 @@
 // inside an iteratively re-weighted L1 loop -- in the configuration the reference asks for (no darkfield) with
 // basicpy's documented defaults, and its definition is oracle/basic_oracle.py (tests compare the two; they also
 // recover a planted gain).  The DIVIDE by the gains is on the hot path (fuse.hip); this estimate runs once per
-// channel before it and is not: <= 64 images are resampled to 128 x 128 and a few hundred iterations of
+// channel before it and is not: <= 80 images are resampled to 128 x 128 and a few hundred iterations of
 // element-wise work + four 128^3 matrix products follow -- microseconds of HBM time, launch-latency bound.
 //
 // Kernels (float32 like basicpy; sums that decide convergence are accumulated in float64):
 //   resample_rows / resample_cols   separable triangle-kernel resize (anti-aliased when shrinking), banded weights
 //   median_kernel                   S0 = per-pixel median over the images
-//   gram_kernel                     A A^T of the [n x 16384] stack (spectral norm on the host: n <= 64)
+//   gram_kernel                     A A^T of the [n x 16384] stack (spectral norm on the host: n <= 80)
 //   s_linear_kernel                 S + sum_i b_i (I_i - b_i S - R_i + Y_i / mu) / eta
 //   s_dct_shrink_kernel             S <- C^T shrink(C S C^T, smoothness / (eta mu)) C   (one workgroup, LDS)
 //   residual_kernel                 R_i <- shrink(I_i - b_i S + Y_i / mu, W_i / mu);  b_i <- max(<S, I_i - R_i + Y_i/mu> / <S,S>, 0)
@@ -36,7 +36,7 @@ namespace {
 
 constexpr int WS = 128;             // working size (basicpy default)
 constexpr int NPIX = WS * WS;
-constexpr int MAX_IMAGES = 64;      // stitcher.py:381-395 collects at most 32 + 32
+constexpr int MAX_IMAGES = 80;      // stitcher.py:381-395: <= 32 per timepoint until MORE than 48 are held -> at most 48 + 32
 constexpr float EPSILON = 0.1f;
 constexpr double RHO = 1.5, MU_COEF = 12.5, MAX_MU_COEF = 1e7, OPT_TOL = 1e-3, REWEIGHT_TOL = 1e-2;
 constexpr int MAX_ITER = 500, MAX_REWEIGHT = 10;

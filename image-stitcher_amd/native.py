@@ -582,7 +582,7 @@ def blosc_encode_planes(planes, chunk_h: int, chunk_w: int, buffers: Optional[Bl
 
 
 def basic_fit(tiles, smoothness_flatfield: float = 1.0, stream=None):
-    """Flatfield estimate of a device stack [n, H, W] (uint8 / uint16, n <= 64) -> (device float32 [H, W], info dict).
+    """Flatfield estimate of a device stack [n, H, W] (uint8 / uint16, n <= 80) -> (device float32 [H, W], info dict).
     Replaces ``BaSiC(get_darkfield=False, smoothness_flatfield=...).fit(images).flatfield`` (stitcher.py:374-377);
     parity with basicpy is UNPINNED (the package is absent offline) -- see include/squidstitch.h.  Synchronises."""
     import torch

@@ -218,9 +218,17 @@ def chunk_jobs(levels: Sequence[np.ndarray], coords: Sequence[tuple], chunks=(1,
     return jobs
 
 
+HOST_CODECS = (None, 'none', 'raw', 'zlib')
+
+
 def emit_chunk(path: str, job, compression: str = 'zlib', level: int = 1) -> int:
     """Write one chunk (all-zero chunks are left to fill_value).  Returns the bytes written."""
     lv, t, c, z, iy, ix, plane, y, x, cy, cx = job
+    if compression not in HOST_CODECS:
+        # 'blosc' chunks are encoded on the device (PlaneStreamWriter / write_ome_zarr): writing zlib bytes under a
+        # .zarray that says blosc would make a store nothing can read
+        raise ValueError(f"emit_chunk compresses on the host with {sorted(str(c) for c in HOST_CODECS)}; {compression!r} chunks "
+                         "come from the device encoder (write_ome_zarr / PlaneStreamWriter)")
     block = plane[y:y + cy, x:x + cx]
     if not block.any():
         return 0
@@ -243,6 +251,9 @@ def write_plane_levels(path: str, levels: Sequence[np.ndarray], coords: Sequence
     """Write the chunks of whole planes (or of one row band of them), every pyramid level given (see
     ``chunk_jobs``), into a store made by ``create_store``.  Returns the bytes written."""
     from concurrent.futures import ThreadPoolExecutor
+    if compression not in HOST_CODECS:
+        raise ValueError(f"write_plane_levels compresses on the host with {sorted(str(c) for c in HOST_CODECS)}; {compression!r} "
+                         "chunks come from the device encoder (write_ome_zarr / PlaneStreamWriter)")
     jobs = chunk_jobs(levels, coords, chunks, row_offset, level_heights)
     if pool is not None:
         return sum(pool.map(lambda j: emit_chunk(path, j, compression, level), jobs))
@@ -362,6 +373,10 @@ class PlaneStreamWriter:
         # D2H copies run on their own stream: the link is full duplex, so batch k leaves the device while
         # batch k+1's tiles arrive and are fused on the caller's stream
         self._copy_stream = torch.cuda.Stream(device=device)
+        # ... and the writer thread fetches a slot's packed frames on a stream of ITS own: on _copy_stream they would
+        # queue behind the wait for the NEXT slot's fusion (submit() parks that wait there) and the disk write-out the
+        # two slots are meant to overlap would serialise
+        self._frame_stream = torch.cuda.Stream(device=device)
         self._free = [threading.Event() for _ in range(slots)]
         for e in self._free:
             e.set()
@@ -406,7 +421,7 @@ class PlaneStreamWriter:
         m = len(coords)
         done = torch.cuda.Event()
         totals = []
-        with torch.cuda.stream(self._copy_stream):
+        with torch.cuda.stream(self._frame_stream):     # the encoder has finished: _dispatch waited for the slot's event
             for enc, (frames, offsets, status) in zip(self._enc[slot], self._host[slot]):
                 if int(status[0]):
                     raise RuntimeError("sq_blosc_encode_planes: output buffer too small")

@@ -246,6 +246,133 @@ def all_pairs(n_rows: int, n_cols: int, height: int, width: int, max_x_overlap: 
     return (np.array(hp, dtype=native.PAIR_DTYPE), hshape), (np.array(vp, dtype=native.PAIR_DTYPE), vshape)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# all-pairs registration sharded over the ranks (north star: "independent overlap pairs ... sharded across the 8 GPUs
+# ... only the small global shift table all-gathered"; SURVEY.md 8e: n_pairs x {dy, dx, err} float64)
+# ---------------------------------------------------------------------------------------------------------------
+PAIR_H, PAIR_V = 0, 1
+
+
+def grid_pair_list(n_rows: int, n_cols: int, present=None) -> List[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
+    """Every adjacent pair of an ``n_rows x n_cols`` grid as (kind, (r, c) reference cell, (r, c) moving cell), in
+    TILE-ROW order: the horizontal pairs of row r, then the vertical pairs from row r to row r + 1, then row r + 1 ...
+    (the reference's own pairs, stitcher.py:455-496, are the centre cell's two).  ``present``: a container of the
+    cells that have a tile; pairs with a missing side are left out.  The order is what makes a contiguous run of
+    the list touch a contiguous band of tile rows (``pairs_of_rank``)."""
+    has = (lambda rc: True) if present is None else (lambda rc: rc in present)
+    out = []
+    for r in range(n_rows):
+        for c in range(n_cols - 1):
+            if has((r, c)) and has((r, c + 1)):
+                out.append((PAIR_H, (r, c), (r, c + 1)))
+        if r + 1 < n_rows:
+            for c in range(n_cols):
+                if has((r, c)) and has((r + 1, c)):
+                    out.append((PAIR_V, (r, c), (r + 1, c)))
+    return out
+
+
+def pairs_of_rank(n_pairs: int, rank: int, world: int) -> List[int]:
+    """Indices into ``grid_pair_list`` owned by ``rank``: ONE contiguous run.  With the list in tile-row order a rank
+    then reads the tiles of its band of rows plus the row below it -- 1/world of the plane + one row -- where a
+    block-cyclic deal of 2 x 1984 pair sides would make every rank of eight read about half of the plane."""
+    from .sharding import contiguous_blocks
+    return contiguous_blocks(n_pairs, rank, world)
+
+
+def cells_of_pairs(pairs, indices) -> List[Tuple[int, int]]:
+    """The grid cells (sorted) the pairs ``indices`` touch: what a rank has to read / upload / min-max."""
+    return sorted({cell for i in indices for cell in pairs[i][1:]})
+
+
+def register_pair_subset(tiles, local_index, pairs, indices, height: int, width: int, max_x_overlap: int,
+                         max_y_overlap: int, normalization='phase', minmax=None) -> np.ndarray:
+    """Register the pairs ``indices`` of ``pairs`` on a device stack ``tiles`` that holds (at least) the cells those
+    pairs touch; ``local_index[(r, c)]`` is a cell's position in the stack.  One batch per direction (their crop
+    shapes differ).  Returns [len(indices), 3] float64 rows {dy, dx, err}: skimage's raw sub-pixel shift of the crop
+    pair (before the reference's ``round`` and ``- w``, stitcher.py:511,524) and its error."""
+    out = np.full((len(indices), 3), np.nan, dtype=np.float64)
+    if not len(indices):
+        return out
+    if minmax is None:
+        minmax = native.tile_minmax(tiles)
+    for kind, make, ov in ((PAIR_H, horizontal_pair, max_x_overlap), (PAIR_V, vertical_pair, max_y_overlap)):
+        slots = [k for k, i in enumerate(indices) if pairs[i][0] == kind]
+        if not slots:
+            continue
+        rows, n0, n1 = [], 0, 0
+        for k in slots:
+            _, a, b = pairs[indices[k]]
+            p, n0, n1 = make(local_index[a], local_index[b], height, width, int(ov))
+            rows.append(p)
+        shifts, err, _ = register_pairs(tiles, np.array(rows, dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+        out[slots, 0:2] = shifts
+        out[slots, 2] = err
+    return out
+
+
+def pair_table_medians(pairs, table: np.ndarray, height: int, width: int, max_x_overlap: int, max_y_overlap: int,
+                       n_rows: int, scan_pattern: str = 'Unidirectional') -> dict:
+    """The reference's state (h_shift, v_shift[, h_shift_rev, h_shift_rev_odd]) from the pair table: every pair's
+    shift converted exactly as the reference converts its centre pair's (python ``round``, ``- w``;
+    stitcher.py:511,524), then the per-axis LOWER median (stays an integer) over the pairs of a direction; with an
+    S-Pattern the rows of the centre row's parity give h_shift and the others h_shift_rev (:486-496).  Pure host
+    arithmetic on the gathered table, so every rank arrives at the same integers.  Returns only the keys a pair
+    was found for (a grid of one row has no v_shift), like the reference leaves the others at their defaults."""
+    def median_int(values):
+        return int(np.sort(np.asarray(values))[(len(values) - 1) // 2])
+
+    def med2(rows):
+        return (median_int([s[0] for s in rows]), median_int([s[1] for s in rows]))
+
+    h_n1 = placement.horizontal_crop_origins(height, width, int(max_x_overlap))[1] if any(p[0] == PAIR_H for p in pairs) else 0
+    v_n0 = placement.vertical_crop_origins(height, width, int(max_y_overlap))[0] if any(p[0] == PAIR_V for p in pairs) else 0
+    cy = (n_rows - 1) // 2
+    s_pattern = scan_pattern == 'S-Pattern'
+    fwd, rev, ver = [], [], []
+    for (kind, a, _), row in zip(pairs, np.asarray(table, dtype=np.float64)):
+        if not (np.isfinite(row[0]) and np.isfinite(row[1])):
+            continue
+        if kind == PAIR_H:
+            s = horizontal_shift_from(row[:2], h_n1)
+            (rev if (s_pattern and a[0] % 2 != cy % 2) else fwd).append(s)
+        else:
+            ver.append(vertical_shift_from(row[:2], v_n0))
+    out = {}
+    if fwd:
+        out['h_shift'] = med2(fwd)
+    if rev:
+        out['h_shift_rev'] = med2(rev)
+        out['h_shift_rev_odd'] = int(cy % 2 == 0)
+    if ver:
+        out['v_shift'] = med2(ver)
+    return out
+
+
+def shifts_from_pair_table(pairs, table, height, width, max_x_overlap, max_y_overlap, n_rows,
+                           scan_pattern: str = 'Unidirectional') -> Shifts:
+    """``pair_table_medians`` as a Shifts (absent directions at the reference's defaults)."""
+    return Shifts(**pair_table_medians(pairs, table, height, width, max_x_overlap, max_y_overlap, n_rows, scan_pattern))
+
+
+def register_all_pairs_sharded(pairs, load_cells, height: int, width: int, max_x_overlap: int, max_y_overlap: int,
+                               normalization='phase', rank: int = 0, world: int = 1, device=None, group=None) -> np.ndarray:
+    """All-pairs registration with the pairs dealt over the ranks.  ``pairs`` = ``grid_pair_list(...)`` (identical on
+    every rank); ``load_cells(cells) -> device stack [len(cells), H, W]`` brings in exactly the tiles THIS rank's
+    pairs touch (files -> H2D in the product, the device generator in the bench).  Every rank registers its run of
+    pairs; the [n_pairs, 3] float64 table {dy, dx, err} is all-gathered (RCCL over xGMI with the nccl backend; the
+    only collective) and returned whole on every rank.  Nothing else is exchanged."""
+    from . import sharding
+    mine = pairs_of_rank(len(pairs), rank, world)
+    cells = cells_of_pairs(pairs, mine)
+    local = np.zeros((0, 3), dtype=np.float64)
+    if mine:
+        tiles = load_cells(cells)
+        local = register_pair_subset(tiles, {c: i for i, c in enumerate(cells)}, pairs, mine, height, width,
+                                     max_x_overlap, max_y_overlap, normalization)
+    return sharding.all_gather_pair_table(local, len(pairs), rank, world, device=device, group=group)
+
+
 def consensus_shift(shifts: np.ndarray, errors: np.ndarray) -> Tuple[float, float]:
     """Robust per-axis median of a batch of pair shifts (all-pairs extension)."""
     ok = np.isfinite(errors)

@@ -152,6 +152,47 @@ def all_gather_shift_table(local_rows: np.ndarray, device=None, group=None) -> n
     return all_gather_shift_table_async(local_rows, device, group).result()
 
 
+PAIR_ROW = 3    # dy, dx, err (float64) of one registered pair (all-pairs mode)
+
+
+def all_gather_pair_table(local_rows: np.ndarray, n_pairs: int, rank: int, world: int, device=None, group=None) -> np.ndarray:
+    """The all-pairs shift table: rank ``r`` registered the contiguous run ``contiguous_blocks(n_pairs, r, world)`` of
+    the pair list and contributes its [k_r, 3] float64 rows {dy, dx, err}; every rank gets the whole [n_pairs, 3] table
+    back in pair order.  Runs differ in length by at most one, so the rows travel in equal slots of ceil(n_pairs /
+    world) rows (the spare one NaN) through ONE all_gather_into_tensor -- 32x32 grid: 1984 pairs x 24 B = 47 KB,
+    latency-bound over xGMI.  Single process: the input."""
+    import torch
+    import torch.distributed as dist
+    import os
+    local_rows = np.ascontiguousarray(local_rows, dtype=np.float64).reshape(-1, PAIR_ROW)
+    mine = contiguous_blocks(n_pairs, rank, world)
+    if len(local_rows) != len(mine):
+        raise ValueError(f"rank {rank} owns {len(mine)} of {n_pairs} pairs but brought {len(local_rows)} rows")
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and not os.environ.get('SQ_DIST_FORCE_COLLECTIVE')):
+        if world != 1:
+            raise RuntimeError(f"world of {world} ranks but no process group: nothing to gather the pair table over")
+        return local_rows.copy()
+    if dist.get_world_size(group) != world:
+        raise ValueError(f"world {world} != process group size {dist.get_world_size(group)}")
+    slot = -(-n_pairs // world) if n_pairs else 0
+    if slot == 0:
+        return np.zeros((0, PAIR_ROW), dtype=np.float64)
+    padded = np.full((slot, PAIR_ROW), np.nan, dtype=np.float64)
+    padded[:len(local_rows)] = local_rows
+    t = torch.from_numpy(padded)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world * slot, PAIR_ROW), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    gathered = out.cpu().numpy().reshape(world, slot, PAIR_ROW)
+    table = np.empty((n_pairs, PAIR_ROW), dtype=np.float64)
+    for r in range(world):
+        idx = contiguous_blocks(n_pairs, r, world)
+        table[idx] = gathered[r, :len(idx)]
+    return table
+
+
 def first_valid(table: np.ndarray) -> Optional[Shifts]:
     """The reference registers once and applies the result everywhere (stitcher.py:1244-1246):
     the first valid row of the gathered table is that result."""

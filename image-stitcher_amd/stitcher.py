@@ -391,52 +391,39 @@ class Stitcher:
     def _calculate_shifts_all_pairs(self, t, region, xs, ys, max_x_overlap, max_y_overlap):
         """Extension: registration over ALL adjacent tile pairs of the registration plane (batched on the
         device), reduced to the reference's state (h_shift, v_shift[, h_shift_rev]) by a per-axis median --
-        a single bad tile (dust, empty field) then cannot derail the whole mosaic."""
+        a single bad tile (dust, empty field) then cannot derail the whole mosaic.
+
+        Under ``run()`` with several ranks (``self._pair_ranks`` = (rank, world)) the pairs are SHARDED: every rank
+        takes one contiguous run of the pair list (tile-row order), reads and uploads only the tiles its pairs touch,
+        and the [n_pairs, 3] float64 table {dy, dx, err} is all-gathered (registration.register_all_pairs_sharded);
+        the medians are host arithmetic on that table, so every rank sets the same integers."""
         import torch
         n_rows, n_cols = len(ys), len(xs)
         at = {}
         for v in self.get_region_data(t, region).values():
             if v['channel'] == self.registration_channel and v['z_level'] == self.registration_z_level:
                 at[(ys.index(v['y']), xs.index(v['x']))] = v['filepath']
-        index, images = {}, []
-        for key in sorted(at):
-            index[key] = len(images)
-            img = read_image(at[key])
-            images.append(img if img.ndim == 2 else img[..., 0])
-        if not images:
+        if not at:
             return
-        tiles = torch.from_numpy(np.ascontiguousarray(np.stack(images))).to(self.device)
-        minmax = native.tile_minmax(tiles)
-        cy = (n_rows - 1) // 2
-        s_pattern = self.scan_pattern == 'S-Pattern'
+        rank, world = getattr(self, '_pair_ranks', None) or (0, 1)
+        pairs = registration.grid_pair_list(n_rows, n_cols, present=at)
 
-        def median_int(values):
-            return int(np.sort(np.asarray(values))[(len(values) - 1) // 2])    # lower median: stays an integer
+        def load_cells(cells):
+            def one(cell):
+                img = read_image(at[cell])
+                return img if img.ndim == 2 else img[..., 0]
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+                images = list(pool.map(one, cells))
+            return torch.from_numpy(np.ascontiguousarray(np.stack(images))).to(self.device)
 
-        def reduce(pairs_rc, make, convert, width):
-            rows = [(make(index[a], index[b], self.input_height, self.input_width, width), a) for a, b in pairs_rc
-                    if a in index and b in index]
-            if not rows:
-                return None, []
-            n0, n1 = rows[0][0][1], rows[0][0][2]
-            batch = np.array([r[0][0] for r in rows], dtype=native.PAIR_DTYPE)
-            shifts, _, _ = registration.register_pairs(tiles, batch, n0, n1, 10, self.normalization, minmax)
-            return [convert(sft, n1 if make is registration.horizontal_pair else n0) for sft in shifts], [r[1] for r in rows]
-
-        h_pairs = [((r, c), (r, c + 1)) for r in range(n_rows) for c in range(n_cols - 1)]
-        v_pairs = [((r, c), (r + 1, c)) for r in range(n_rows - 1) for c in range(n_cols)]
-        hs, h_at = reduce(h_pairs, registration.horizontal_pair, registration.horizontal_shift_from, max_x_overlap)
-        vs, _ = reduce(v_pairs, registration.vertical_pair, registration.vertical_shift_from, max_y_overlap)
-        if hs:
-            fwd = [s for s, (r, _) in zip(hs, h_at) if not s_pattern or r % 2 == cy % 2]
-            rev = [s for s, (r, _) in zip(hs, h_at) if s_pattern and r % 2 != cy % 2]
-            if fwd:
-                self.h_shift = (median_int([s[0] for s in fwd]), median_int([s[1] for s in fwd]))
-            if rev:
-                self.h_shift_rev = (median_int([s[0] for s in rev]), median_int([s[1] for s in rev]))
-                self.h_shift_rev_odd = cy % 2 == 0
-        if vs:
-            self.v_shift = (median_int([s[0] for s in vs]), median_int([s[1] for s in vs]))
+        table = registration.register_all_pairs_sharded(
+            pairs, load_cells, self.input_height, self.input_width, max_x_overlap, max_y_overlap, self.normalization,
+            rank=rank, world=world, device=sharding.collective_device(self))
+        self.pair_table = table     # [n_pairs, {dy, dx, err}] float64, pair order = registration.grid_pair_list
+        med = registration.pair_table_medians(pairs, table, self.input_height, self.input_width, max_x_overlap,
+                                              max_y_overlap, n_rows, self.scan_pattern)
+        for name, value in med.items():
+            setattr(self, name, bool(value) if name == 'h_shift_rev_odd' else tuple(value))
 
     # -------------------------------------------------------------- flatfield
     def apply_flatfield_correction(self, tile, channel_idx):
@@ -818,8 +805,9 @@ class Stitcher:
         return output_path
 
     def _run_region_by_planes(self, timepoint, region, rank, world):
-        """One region shared by all ranks.  With at least as many (channel, z) planes as ranks, plane
-        p goes to rank p % world; with fewer, every plane is cut into row bands of 512 * 2^(levels-1) level-0 rows
+        """One region shared by all ranks.  With at least as many (channel, z) planes as ranks, every
+        rank takes one contiguous run of planes (sharding.contiguous_blocks: a channel's z planes stay together);
+        with fewer, every plane is cut into row bands of 512 * 2^(levels-1) level-0 rows
         (sharding.row_bands: whole chunk rows at every pyramid level) and the (plane, band) units are dealt instead
         -- a rank then reads only the tiles that reach into its bands.  Chunks of an OME-Zarr store span neither
         planes nor bands, so the ranks write into one store without locking."""
@@ -929,11 +917,19 @@ class Stitcher:
                 with open(os.path.join(self.output_folder, 'flatfield_info.json'), 'w') as fh:
                     json.dump(self.flatfield_info, fh, indent=1)
         coll = sharding.collective_device(self)
+        # all-pairs registration (--dynamic-registration) is sharded by PAIR: every rank registers its run of the pair
+        # list and the float64 pair table is all-gathered (registration.register_all_pairs_sharded); the reference's
+        # centre-pair scheme is three tiles' worth of work and stays on rank 0, its 8-int32 row all-gathered
+        pair_sharded = world > 1 and bool(getattr(self, 'dynamic_registration', False))
         if self.use_registration and not self.per_region_registration:
-            if rank == 0:
+            if rank == 0 or pair_sharded:
                 print(f"\nCalculating shifts on region {self.regions[0]}...")
-                self.calculate_shifts(self.timepoints[0], self.regions[0])
-            if world > 1:
+                self._pair_ranks = (rank, world) if pair_sharded else None
+                try:
+                    self.calculate_shifts(self.timepoints[0], self.regions[0])
+                finally:
+                    self._pair_ranks = None
+            if world > 1 and not pair_sharded:
                 row = sharding.shifts_to_row(self._shifts() if rank == 0 else None)
                 table = sharding.all_gather_shift_table(row[None], device=coll)
                 self._apply_shifts(sharding.first_valid(table))
@@ -946,7 +942,16 @@ class Stitcher:
             # fewer (timepoint, region) units than GPUs: share each region by (channel, z) plane
             # instead -- every rank fuses its planes and writes their chunks into the common store
             for i, (timepoint, region) in enumerate(units):
-                if self.per_region_registration:
+                if self.per_region_registration and pair_sharded:
+                    # the ranks share this region anyway: they share its pairs too
+                    self._pair_ranks = (rank, world)
+                    try:
+                        self.calculate_shifts(timepoint, region)
+                    finally:
+                        self._pair_ranks = None
+                    if rank == 0:
+                        my_rows[i] = sharding.shifts_to_row(self._shifts())
+                elif self.per_region_registration:
                     if rank == 0:
                         self.calculate_shifts(timepoint, region)
                         my_rows[i] = sharding.shifts_to_row(self._shifts())

@@ -237,7 +237,7 @@ int sq_blosc_encode_planes(const void *planes_dev, int64_t plane_stride, int64_t
 /* ------------------------------------------------------------------------------------------
  * Flatfield ESTIMATE: replaces basicpy.BaSiC(get_darkfield=False, smoothness_flatfield=s).fit(images).flatfield
  * in Stitcher.get_flatfields (stitcher.py:365-419; the call is :374-377) for one channel's sample of tiles
- * (<= 64: the reference collects at most 32 per timepoint and stops above 48, :381-395).
+ * (<= 80: the reference adds at most 32 per timepoint and stops once it holds MORE than 48, :381-395 -> up to 48 + 32).
  * PARITY UNPINNED: basicpy is an absent, un-pinned third-party package; this is the published BaSiC algorithm
  * (Peng et al. 2017; LADMAP + re-weighted L1, no darkfield, basicpy's documented defaults) as defined by
  * oracle/basic_oracle.py.  Not on the hot path (the divide by the result is: sq_fuse_planes).

@@ -93,3 +93,18 @@ def test_both_readers_on_hand_built_frames(typesize, dont_split):
     assert blosc_ref.blosc_decompress(f) == raw and omezarr.blosc_decode(f) == raw
     with pytest.raises(ValueError):
         blosc_ref.blosc_decompress(f[:-1])
+
+
+def test_host_chunk_writers_refuse_codecs_they_do_not_implement(tmp_path):
+    """emit_chunk / write_plane_levels used to fall through to zlib for anything that was not 'none' --
+    'blosc' (the Stitcher default, encoded on the DEVICE) then left zlib bytes under a .zarray that says blosc."""
+    from image_stitcher_amd import omezarr
+    plane = np.arange(64 * 64, dtype=np.uint16).reshape(1, 64, 64)
+    for bad in ('blosc', 'lz4', 'zstd'):
+        with pytest.raises(ValueError, match='device encoder'):
+            omezarr.write_plane_levels(str(tmp_path / 's'), [plane], [(0, 0, 0)], (1, 1, 1, 32, 32), compression=bad)
+        with pytest.raises(ValueError, match='device encoder'):
+            omezarr.emit_chunk(str(tmp_path / 's'), (0, 0, 0, 0, 0, 0, plane[0], 0, 0, 32, 32), bad)
+    assert not (tmp_path / 's').exists()
+    for ok in ('zlib', 'none', None):
+        assert omezarr.write_plane_levels(str(tmp_path / f's_{ok}'), [plane], [(0, 0, 0)], (1, 1, 1, 32, 32), compression=ok) > 0

@@ -342,6 +342,38 @@ def test_get_flatfields_estimators_and_basicpy_delegation(tmp_path, monkeypatch)
     assert all(float(st.flatfields[i][0, 0]) == 1.25 for i in range(3)) and float(st.flatfields[3][0, 0]) == 1.0
 
 
+def test_flatfield_sample_can_reach_80_images_and_the_device_fit_takes_them(tmp_path, monkeypatch):
+    """the reference adds min(32, n) shuffled tiles per timepoint and stops once it holds MORE than 48
+    (stitcher.py:381-395).  24 tiles per timepoint -> 24, 48, 72 images (48 is not > 48); the most it can reach is
+    48 + 32 = 80.  The device fit's workspace accepts up to 80 and refuses 81."""
+    import sys
+    import types
+    from image_stitcher_amd import native
+    from image_stitcher_amd.stitcher import Stitcher
+    spec = synth.GridSpec(rows=4, cols=6, tile_h=32, tile_w=48, ov_y=8, ov_x=8, seed=5, nt=4,
+                          channels=('Fluorescence 488 nm Ex',))
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec, root)
+    counts = []
+
+    class FakeBaSiC:
+        def __init__(self, **kw):
+            pass
+
+        def fit(self, images):
+            counts.append(len(images))
+            self.flatfield = np.ones(images.shape[1:], dtype=np.float64)
+
+    monkeypatch.setitem(sys.modules, 'basicpy', types.SimpleNamespace(BaSiC=FakeBaSiC))
+    st = Stitcher(StitchingParameters(input_folder=root, apply_flatfield=True))
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    st.get_flatfields()
+    assert counts == [72]                     # 24 + 24 + 24: the fourth timepoint is not touched
+    L = native.lib()
+    assert L.sq_basic_workspace_bytes(72, 32, 48) > 0 and L.sq_basic_workspace_bytes(80, 2048, 2048) > 0
+    assert L.sq_basic_workspace_bytes(81, 32, 48) < 0 and b'1..80' in L.sq_last_error()
+
+
 @pytest.mark.parametrize('rows,cols', [(1, 3), (3, 1), (1, 1)])
 def test_degenerate_grids_behave_like_the_reference(tmp_path, rows, cols):
     """One row, one column or one tile: coordinate-only placement works; with -r the reference indexes

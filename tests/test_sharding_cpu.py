@@ -134,3 +134,130 @@ def test_shift_table_json_shared_region_three_ranks(tmp_path):
         assert doc['per_region_registration'] is True and len(doc['shifts']) == n
         for i, e in enumerate(doc['shifts']):
             assert e['h_shift'] == [i, -100 - i] and e['v_shift'] == [-200 - i, i]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# all-pairs registration sharded by pair (north star; SURVEY.md 8e: n_pairs x {dy, dx, err} float64 all-gather)
+# ---------------------------------------------------------------------------------------------------------------
+def test_pair_list_is_in_tile_row_order_and_runs_touch_row_bands():
+    from image_stitcher_amd import registration as R
+    pairs = R.grid_pair_list(32, 32)
+    assert len(pairs) == 2 * 32 * 31 == 1984                                   # SURVEY 8e's figure
+    assert sum(p[0] == R.PAIR_H for p in pairs) == sum(p[0] == R.PAIR_V for p in pairs) == 992
+    assert len(set(pairs)) == len(pairs)
+    for kind, a, b in pairs:
+        assert b == ((a[0], a[1] + 1) if kind == R.PAIR_H else (a[0] + 1, a[1]))
+    assert [p[1][0] for p in pairs] == sorted(p[1][0] for p in pairs)          # reference cells in tile-row order
+    covered = []
+    for world in (1, 2, 3, 8):
+        most = 0
+        for r in range(world):
+            mine = R.pairs_of_rank(len(pairs), r, world)
+            covered.extend(mine)
+            cells = R.cells_of_pairs(pairs, mine)
+            rows = {c[0] for c in cells}
+            assert rows == set(range(min(rows), max(rows) + 1))               # one band of tile rows
+            most = max(most, len(cells))
+        assert sorted(covered) == list(range(len(pairs)))
+        covered.clear()
+        # a rank reads its band + at most two boundary rows, not the plane: 8 ranks -> <= (4 + 2) rows of 32
+        assert most <= (32 // world + 2) * 32 or world == 1
+    # a missing tile removes exactly the pairs it is part of
+    present = {(r, c) for r in range(3) for c in range(3)} - {(1, 1)}
+    left = R.grid_pair_list(3, 3, present)
+    assert len(left) == 12 - 4 and all((1, 1) not in p[1:] for p in left)
+    assert R.grid_pair_list(1, 1) == [] and len(R.grid_pair_list(1, 4)) == 3 and len(R.grid_pair_list(4, 1)) == 3
+
+
+def test_pair_table_medians_convert_like_the_reference_and_take_the_lower_median():
+    from image_stitcher_amd import registration as R
+    pairs = R.grid_pair_list(3, 3)
+    n0h, n1h = 1024, 256          # 2048^2 tiles, overlap crop 256: horizontal crop 1024 x 256, vertical 256 x 1024
+    table = np.full((len(pairs), 3), 0.0)
+    for i, (kind, a, b) in enumerate(pairs):
+        table[i, :2] = (3.0, 12.0) if kind == R.PAIR_H else (12.0, -2.0)     # raw skimage shifts of the crops
+    table[0, :2] = (40.0, 90.0)             # one derailed pair: the median ignores it
+    table[3, :2] = (np.nan, np.nan)         # a pair that produced nothing is left out
+    med = R.pair_table_medians(pairs, table, 2048, 2048, 256, 256, 3)
+    assert med == {'h_shift': (3, 12 - n1h), 'v_shift': (12 - 256, -2)}      # round(s0), round(s1 - w) / round(s0 - w), round(s1)
+    s = R.shifts_from_pair_table(pairs, table, 2048, 2048, 256, 256, 3)
+    assert s == Shifts((3, -244), (-244, -2))
+    # python round = banker's rounding on the float64 (stitcher.py:511): 2.5 -> 2, 3.5 -> 4
+    t2 = table.copy()
+    t2[[i for i, p in enumerate(pairs) if p[0] == R.PAIR_H], 0] = 2.5
+    assert R.pair_table_medians(pairs, t2, 2048, 2048, 256, 256, 3)['h_shift'][0] == 2
+    # S-Pattern: rows of the centre row's parity -> h_shift, the others -> h_shift_rev (stitcher.py:486-496)
+    t3 = table.copy()
+    for i, (kind, a, b) in enumerate(pairs):
+        if kind == R.PAIR_H and a[0] % 2 == 0:
+            t3[i, :2] = (-1.0, 20.0)
+    med = R.pair_table_medians(pairs, t3, 2048, 2048, 256, 256, 3, 'S-Pattern')
+    assert med['h_shift'] == (3, -244) and med['h_shift_rev'] == (-1, 20 - 256) and med['h_shift_rev_odd'] == 0
+    # even count: the LOWER median, so the result is one of the measured integers
+    two = R.grid_pair_list(1, 3)
+    assert R.pair_table_medians(two, np.array([[1.0, 10.0, 0], [5.0, 30.0, 0]]), 2048, 2048, 256, 256, 1)['h_shift'] == (1, 10 - 256)
+    # a single row has no vertical pairs: v_shift is not reported (the caller keeps the reference's default)
+    assert 'v_shift' not in R.pair_table_medians(two, np.zeros((2, 3)), 2048, 2048, 256, 256, 1)
+
+
+def _pair_table_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from image_stitcher_amd import sharding as sh
+        for n_pairs in (1984, 7, 2, 0):       # 1984 = the 32x32 grid; 7 and 2: uneven runs, ranks with nothing
+            full = np.arange(n_pairs * 3, dtype=np.float64).reshape(n_pairs, 3) * 0.1 - 5.0
+            mine = sh.contiguous_blocks(n_pairs, rank, world)
+            table = sh.all_gather_pair_table(full[mine], n_pairs, rank, world)
+            assert table.dtype == np.float64 and table.shape == (n_pairs, 3)
+            np.testing.assert_array_equal(table, full)                      # bit for bit, pair order, on every rank
+        with pytest.raises(ValueError):
+            sh.all_gather_pair_table(np.zeros((1, 3)), 1984, rank, world)   # not this rank's run
+        open(os.path.join(out_dir, f'pairs_ok{rank}'), 'w').close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_pair_table_all_gather_gloo(tmp_path, world):
+    mp.spawn(_pair_table_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f'pairs_ok{r}').exists() for r in range(world))
+    # single process: identity, and a world without a process group is an error rather than a silent partial table
+    full = np.arange(12, dtype=np.float64).reshape(4, 3)
+    np.testing.assert_array_equal(sharding.all_gather_pair_table(full, 4, 0, 1), full)
+    with pytest.raises(RuntimeError):
+        sharding.all_gather_pair_table(full[:2], 4, 0, 2)
+
+
+def test_bench_launcher_argv(monkeypatch):
+    """`python bench.py --gpus N` starts its own ranks: the launcher's command line, without a GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = bench.launch_argv(4, ['--gpus', '4', '--steps', '3', '--warmup', '1'], 29555)
+    assert argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in argv and '--nproc-per-node=4' in argv
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1' and argv[argv.index('--master-port') + 1] == '29555'
+    k = argv.index(os.path.join(ROOT, 'bench.py'))
+    assert argv[k + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert 1024 < bench.free_port() < 65536
+    # the launcher relays the children's status and never imports torch.cuda in the parent
+    calls = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None):
+            calls['cmd'], calls['env'] = cmd, env
+
+        def wait(self):
+            return 3
+    import subprocess
+    monkeypatch.setattr(subprocess, 'Popen', FakeProc)
+    assert bench.launch_ranks(2, ['--gpus', '2']) == 3
+    assert calls['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and '--nproc-per-node=2' in calls['cmd']
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '1'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3 and calls['cmd'][-4:] == ['--gpus', '2', '--steps', '1']
