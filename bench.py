@@ -454,7 +454,7 @@ def cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas
     take = -(-n // n_groups)
     sample = sorted({gi * per + k for gi in range(n_groups) for k in range(min(take, per))})[:n] if n < total else list(range(total))
     n = len(sample)
-    host = tiles[sample].cpu().numpy()
+    host = np.stack([tiles[p].cpu().numpy() for p in sample])      # (torch has no uint16 fancy indexing on the device)
     flats = [flat_list[p].cpu().numpy() if flat_list else None for p in sample]
     t0 = time.perf_counter()
     mx, my = O.max_overlaps(xs, ys, TILE, TILE, spec.pixel_size_um, spec.pixel_binning)

@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 REGION_CASES = sorted(os.path.splitext(os.path.basename(p))[0]
                       for p in glob.glob(os.path.join(GOLDEN, '*.json'))
-                      if not os.path.basename(p).startswith('pcc_'))
+                      if not os.path.basename(p).startswith(('pcc_', 'blosc_')))
 
 
 def sha(a):

@@ -108,3 +108,33 @@ def test_host_chunk_writers_refuse_codecs_they_do_not_implement(tmp_path):
     assert not (tmp_path / 's').exists()
     for ok in ('zlib', 'none', None):
         assert omezarr.write_plane_levels(str(tmp_path / f's_{ok}'), [plane], [(0, 0, 0)], (1, 1, 1, 32, 32), compression=ok) > 0
+
+
+def test_both_readers_decode_genuine_c_blosc_frames():
+    """frames produced by the GENUINE c-blosc 1.21.0 (imagecodecs 2021.8.26 under the authoring
+    container's /opt/conda/bin/python3.9; tests/golden/make_blosc_golden.py cblosc) -- LZ4 with and without byte
+    shuffle, levels 1 / 5 / 9, typesize 1 / 2, split streams, an incompressible (memcpy'd) chunk, a 42-byte chunk --
+    decode to the seeded raw chunk with BOTH readers of this repo.  That pins the readers the device encoder's tests
+    lean on to third-party output."""
+    import json
+    import os
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, golden)
+    import make_blosc_golden as G
+    with open(os.path.join(golden, 'blosc_cblosc_frames.json')) as fh:
+        index = json.load(fh)
+    assert index['encoder'] == 'c-blosc 1.21.0'
+    frames = np.load(os.path.join(golden, 'blosc_cblosc_frames.npz'))
+    seen_flags = set()
+    for e in index['frames']:
+        frame = frames[e['name']].tobytes()
+        raw = G.chunk(e['kind'], e['h'], e['w'], e['dtype'], e['seed']).tobytes()
+        assert G.sha(raw) == e['raw_sha256'] and len(frame) == e['cbytes']       # the seeded chunk is the one c-blosc saw
+        hd = blosc_ref.parse_header(frame)
+        assert hd['nbytes'] == len(raw) and hd['cbytes'] == len(frame) and hd['typesize'] == np.dtype(e['dtype']).itemsize
+        assert blosc_ref.blosc_decompress(frame) == raw, e['name']
+        assert omezarr.blosc_decode(frame) == raw, e['name']
+        seen_flags.add(e['flags'])
+    assert {0x21, 0x20, 0x23} <= seen_flags          # shuffled, unshuffled, memcpy'd -- split (no 0x10) streams throughout
+    assert len(index['frames']) >= 15

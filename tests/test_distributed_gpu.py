@@ -155,7 +155,7 @@ def _pairs_state(root, scan_pattern, run=False):
     st._pair_ranks = (rank, world) if world > 1 else None
     st.calculate_shifts(st.timepoints[0], st.regions[0])
     rev = tuple(st.h_shift_rev) if scan_pattern == 'S-Pattern' else (0, 0)
-    return np.array([*st.h_shift, *st.v_shift, *rev, int(st.h_shift_rev_odd)], dtype=np.int64), np.array(st.pair_table)
+    return np.array([*st.h_shift, *st.v_shift, *rev, int(getattr(st, 'h_shift_rev_odd', 0))], dtype=np.int64), np.array(st.pair_table)
 
 
 def _worker_pairs(rank, world, port, roots, out_dir):

@@ -1,0 +1,416 @@
+// membw_gains: the two structural experiments VERDICT r2 (item 2) asks for, "membw first": the fusion kernel's inner
+// work -- config-3-shaped row segments of Z planes that share one float32 gain image, uint16 pixel / gain -> uint16,
+// the product's Markstein divide -- in three structures, alternated in ONE process on the same buffers:
+//
+//   A  "regs"      the shipped structure (fuse_overwrite_zg_kernel): a workgroup of 4 waves per item of 8 rows, wave w
+//                  rows w, w + 4; per 16-byte slot a lane loads its 8 gains, takes 8 reciprocals, issues the Z planes'
+//                  pixel loads and streams them through the divide: Z loads + Z stores per thread and slot, gains and
+//                  reciprocals in 16 VGPRs.
+//   B  "lds gains" gains staged in LDS per row: the workgroup's threads load the row's gains once, take the
+//                  reciprocals once and write {g, 1/g} to LDS (lane-linear, conflict-free 16-byte units); then every
+//                  WAVE takes a different plane: ONE pixel load + ONE store per thread and slot, the gain pairs by
+//                  ds_read_b128.  Two LDS row buffers, one barrier per row.  ROWS rows per workgroup (8 = an item,
+//                  1 / 2 = the short-lived workgroups of profiles/r02_membw_2d.log's row-wise copy).
+//   C  "lds dma"   structure A with the pixel stream through LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+//                  instruction straight into a per-wave LDS ring, no VGPR destination), read back by ds_read_b128
+//                  when the slot is computed.  (Sources are 16-byte aligned here; the real tiles sit at 2-byte
+//                  phases, which an LDS-DMA could only serve through aligned chunks + v_alignbyte: this variant is
+//                  the upper bound of what that could give.)
+//   (P  plain copy of the same segments, Z planes per thread, no gains: the yardstick.)
+//
+// Geometry: G x G tiles of T x T uint16 (dense), every tile contributes `rows` row segments of S bytes starting at
+// byte src_off; the canvas has an arbitrary pitch (rows at every 16-byte phase inside a 128-byte line); stores are
+// issued so that lane 0 of every store instruction sits on a 128-byte line ("line slots", what the product does).
+// Results of B and C are compared with A's on the device (bit for bit) before anything is timed.
+//   hipcc --offload-arch=gfx950 -O3 membw_gains.hip -o membw_gains ;  ./membw_gains [Z=5] [reps=5]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);     \
+            exit(1);                                                                           \
+        }                                                                                      \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define G1 __attribute__((address_space(1)))
+struct __attribute__((packed)) U4U { u32x4 v; };
+struct __attribute__((packed)) F4U { f32x4 v; };
+
+constexpr int ZMAX = 5;
+struct Geo {
+    const char *src;      // plane z at src + z * src_plane
+    char *dst;            // plane z at dst + z * dst_plane
+    const float *gain;    // T x T
+    size_t src_plane, dst_plane, src_tile, src_pitch, src_off, dst_pitch, dst_ty, dst_tx;
+    int G, T, rows, S, gy0, gx0;   // gain of a segment's first pixel: (gy0, gx0)
+};
+
+__device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+__device__ __forceinline__ float quot(float n, float g, float r) {   // the product's div_u16_normal with the reciprocal given
+    float q = n * r;
+    return fmaf(fmaf(-g, q, n), r, q);
+}
+__device__ __forceinline__ uint32_t quot_pair(uint32_t word, float g0, float g1, float r0, float r1) {
+    const float n0 = (float)(word & 0xFFFFu), n1 = (float)(word >> 16);
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 p = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(quot(n0, g0, r0)), cvt_u32_sat(quot(n1, g1, r1)));
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+}
+__device__ __forceinline__ void st_nt(char *p, u32x4 v) { __builtin_nontemporal_store(v, (G1 u32x4 *)p); }
+
+struct RowAddr {
+    const char *s;   // plane 0 source row
+    char *d;         // plane 0 destination row
+    const char *g;   // gain row (float)
+    int shift;       // 16-byte units between the line boundary before d and d
+};
+__device__ __forceinline__ RowAddr row_of(const Geo &P, int tile, int r) {
+    const int ty = tile / P.G, tx = tile % P.G;
+    RowAddr A;
+    A.s = P.src + (size_t)tile * P.src_tile + P.src_off + (size_t)r * P.src_pitch;
+    A.d = P.dst + (size_t)ty * P.dst_ty + (size_t)tx * P.dst_tx + (size_t)r * P.dst_pitch;
+    A.g = reinterpret_cast<const char *>(P.gain + (size_t)(P.gy0 + r) * P.T + P.gx0);
+    A.shift = (int)(((uintptr_t)A.d & 127) >> 4);
+    return A;
+}
+
+// ---- A: the shipped structure --------------------------------------------------------------------------------
+template <int Z, bool GAINS>
+__global__ __launch_bounds__(256) void k_regs(const Geo P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    for (int j = 0; j < 2; ++j) {
+        const int r = blk * 8 + wave + 4 * j;
+        if (r >= P.rows) break;
+        const RowAddr A = row_of(P, tile, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (64 * k - A.shift >= nvec) break;
+            const int i = lane + 64 * k - A.shift;
+            const bool act = i >= 0 && i < nvec;
+            const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+            float g[8], rc[8];
+            if (GAINS) {
+                const f32x4 a = ((const G1 F4U *)(A.g + o * 2u))->v, b = ((const G1 F4U *)(A.g + o * 2u + 16))->v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[e] = a[e];
+                    g[4 + e] = b[e];
+                }
+            }
+            u32x4 px[Z];
+#pragma unroll
+            for (int z = 0; z < Z; ++z) px[z] = ((const G1 U4U *)(A.s + z * P.src_plane + o))->v;
+            if (GAINS) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rc[c] = __builtin_amdgcn_rcpf(g[c]);
+            }
+#pragma unroll
+            for (int z = 0; z < Z; ++z) {
+                u32x4 ov = px[z];
+                if (GAINS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ov[c] = quot_pair(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                }
+                if (act) st_nt(A.d + z * P.dst_plane + o, ov);
+            }
+        }
+    }
+}
+
+// ---- B: gains staged in LDS, one wave per plane ---------------------------------------------------------------
+// LDS image of a row: [4 components][256 units] float4; unit u = 64 * slot + lane; components g0-3, g4-7, r0-3, r4-7.
+// Lane l of slot k reads unit 64k + l of every component: consecutive lanes, consecutive 16 bytes -- conflict-free.
+template <int Z, int ROWS>
+__global__ __launch_bounds__(64 * Z) void k_lds_gains(const Geo P) {
+    __shared__ f32x4 s_g[2][4][256];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nblk = (P.rows + ROWS - 1) / ROWS;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    const int r0 = blk * ROWS, nr = min(ROWS, P.rows - r0);
+    const int u = threadIdx.x;          // staging unit of this thread (threads >= 256 stage nothing)
+    auto stage_load = [&](const RowAddr &A, f32x4 &a, f32x4 &b) {
+        const int i = (u & 63) + 64 * (u >> 6) - A.shift;
+        const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+        a = ((const G1 F4U *)(A.g + o * 2u))->v;
+        b = ((const G1 F4U *)(A.g + o * 2u + 16))->v;
+    };
+    auto stage_write = [&](int buf, const f32x4 &a, const f32x4 &b) {
+        f32x4 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ra[e] = __builtin_amdgcn_rcpf(a[e]);
+            rb[e] = __builtin_amdgcn_rcpf(b[e]);
+        }
+        s_g[buf][0][u] = a;
+        s_g[buf][1][u] = b;
+        s_g[buf][2][u] = ra;
+        s_g[buf][3][u] = rb;
+    };
+    RowAddr A = row_of(P, tile, r0);
+    f32x4 ga, gb;
+    if (u < 256) {
+        stage_load(A, ga, gb);
+        stage_write(0, ga, gb);
+    }
+    u32x4 px[4];
+    auto px_load = [&](const RowAddr &R) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k - R.shift;
+            const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+            px[k] = ((const G1 U4U *)(R.s + wave * P.src_plane + o))->v;
+        }
+    };
+    px_load(A);
+    for (int j = 0; j < nr; ++j) {
+        __syncthreads();   // row j's gains are in s_g[j & 1]; everybody is done with s_g[(j + 1) & 1]
+        const bool more = j + 1 < nr;
+        RowAddr N = A;
+        if (more) {
+            N = row_of(P, tile, r0 + j + 1);
+            if (u < 256) stage_load(N, ga, gb);
+        }
+        u32x4 ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int un = 64 * k + lane;
+            const f32x4 a = s_g[j & 1][0][un], b = s_g[j & 1][1][un], ra = s_g[j & 1][2][un], rb = s_g[j & 1][3][un];
+            ov[k][0] = quot_pair(px[k][0], a[0], a[1], ra[0], ra[1]);
+            ov[k][1] = quot_pair(px[k][1], a[2], a[3], ra[2], ra[3]);
+            ov[k][2] = quot_pair(px[k][2], b[0], b[1], rb[0], rb[1]);
+            ov[k][3] = quot_pair(px[k][3], b[2], b[3], rb[2], rb[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k - A.shift;
+            if (i >= 0 && i < nvec) st_nt(A.d + wave * P.dst_plane + (uint32_t)i * 16u, ov[k]);
+        }
+        if (more) {
+            px_load(N);
+            if (u < 256) stage_write((j + 1) & 1, ga, gb);
+            A = N;
+        }
+    }
+}
+
+// ---- C: structure A, pixel stream through LDS-DMA -------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int Z>
+__global__ __launch_bounds__(256) void k_lds_dma(const Geo P) {
+    // per wave: a ring of 2 slots x Z planes x 1 KiB
+    __shared__ u32x4 s_px[4][2][Z][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    // steps of this wave: (row j, slot k), j = 0, 1; the DMA of step t + 1 is issued before step t is computed
+    RowAddr R[2];
+    int nrow = 0;
+    for (int j = 0; j < 2; ++j) {
+        const int r = blk * 8 + wave + 4 * j;
+        if (r < P.rows) R[nrow++] = row_of(P, tile, r);
+    }
+    if (!nrow) return;
+    const int steps = nrow * 4;
+    auto issue = [&](int t) {
+        const RowAddr &A = R[t >> 2];
+        const int i = lane + 64 * (t & 3) - A.shift;
+        const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+#pragma unroll
+        for (int z = 0; z < Z; ++z) {
+            const uint32_t dst = (uint32_t)(uintptr_t)&s_px[wave][t & 1][z][0];
+            glds16(A.s + z * P.src_plane + o, dst);
+        }
+    };
+    issue(0);
+    for (int t = 0; t < steps; ++t) {
+        const RowAddr &A = R[t >> 2];
+        const int i = lane + 64 * (t & 3) - A.shift;
+        const bool act = i >= 0 && i < nvec;
+        const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+        const f32x4 a = ((const G1 F4U *)(A.g + o * 2u))->v, b = ((const G1 F4U *)(A.g + o * 2u + 16))->v;
+        if (t + 1 < steps) {
+            issue(t + 1);
+            // the Z DMAs of step t are older than the Z of step t + 1 (and than the two gain loads? no: those were issued
+            // before) -- wait until only step t + 1's are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Z) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        float g[8], rc[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = a[e];
+            g[4 + e] = b[e];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rc[c] = __builtin_amdgcn_rcpf(g[c]);
+#pragma unroll
+        for (int z = 0; z < Z; ++z) {
+            const u32x4 px = s_px[wave][t & 1][z][lane];
+            u32x4 ov;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ov[c] = quot_pair(px[c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+            if (act) st_nt(A.d + z * P.dst_plane + o, ov);
+        }
+        // the ring slot (t & 1) is overwritten by the DMA of step t + 2, issued in iteration t + 1 after this wave's own
+        // ds_reads above have returned (their results were consumed by the stores' operands)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+__global__ void k_compare(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *bad) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += a[i] != b[i];
+    if (mine) atomicAdd(bad, mine);
+}
+__global__ void k_init(uint32_t *p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        p[i] = x;
+    }
+}
+__global__ void k_init_gain(float *g, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = 0.8f + 0.4f * (float)((i * 2654435761u >> 8) & 0xFFFF) / 65536.0f;
+}
+
+template <typename F>
+static double time_ms(F launch, int reps) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    launch();
+    CK(hipDeviceSynchronize());
+    double best = 1e30, sum = 0;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(a));
+        launch();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    CK(hipGetLastError());
+    (void)sum;
+    return best;
+}
+
+int main(int argc, char **argv) {
+    constexpr int Z = ZMAX;
+    const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    // plane-stride experiments: extra bytes between consecutive planes of the tiles / of the canvas (multiples of 16);
+    // quick = 1: only P, A and B(8) per round
+    const size_t src_pad = argc > 2 ? (size_t)atoll(argv[2]) : 0, dst_pad = argc > 3 ? (size_t)atoll(argv[3]) : 0;
+    const bool quick = argc > 4 && atoi(argv[4]);
+    const int G = 16, T = 2048;
+    Geo P{};
+    P.G = G;
+    P.T = T;
+    P.rows = 1800;
+    P.S = 3600;
+    P.src_tile = (size_t)T * T * 2;
+    P.src_pitch = 4096;
+    P.src_off = 124 * 4096 + 240;            // 16-byte aligned source (C needs it); the phase costs ~2 % (r02_membw_2d.log)
+    P.gy0 = 124;
+    P.gx0 = 120;
+    P.dst_pitch = (size_t)G * P.S + 560;     // rows at every 16-byte phase of a line
+    P.dst_tx = P.S;
+    P.dst_ty = (size_t)P.rows * P.dst_pitch;
+    P.src_plane = (size_t)G * G * P.src_tile + src_pad;
+    P.dst_plane = (((size_t)G * P.rows * P.dst_pitch) + 4095) / 4096 * 4096 + dst_pad;
+    char *src, *dst, *ref;
+    float *gain;
+    unsigned long long *bad;
+    CK(hipMalloc(&src, Z * P.src_plane));
+    CK(hipMalloc(&dst, Z * P.dst_plane));
+    CK(hipMalloc(&ref, Z * P.dst_plane));
+    CK(hipMalloc(&gain, (size_t)T * T * 4));
+    CK(hipMalloc(&bad, 8));
+    hipLaunchKernelGGL(k_init, dim3(4096), dim3(256), 0, 0, (uint32_t *)src, Z * P.src_plane / 4, 12345u);
+    hipLaunchKernelGGL(k_init_gain, dim3(1024), dim3(256), 0, 0, gain, (size_t)T * T);
+    CK(hipMemset(dst, 0, Z * P.dst_plane));
+    CK(hipMemset(ref, 0, Z * P.dst_plane));
+    CK(hipDeviceSynchronize());
+    P.src = src;
+    P.gain = gain;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs; %d planes of a %dx%d grid of %d x %d-byte segments, canvas pitch %zu; plane strides: tiles %zu (+%zu), canvas %zu (+%zu)\n",
+           prop.name, prop.multiProcessorCount, Z, G, G, P.rows, P.S, P.dst_pitch, P.src_plane, src_pad, P.dst_plane, dst_pad);
+    const double moved = 2.0 * Z * G * G * (double)P.rows * P.S;   // pixel bytes read + written (gains: + T*T*4 once, not counted)
+    const unsigned items8 = (unsigned)(G * G * ((P.rows + 7) / 8));
+    auto report = [&](const char *name, double ms, const char *check) {
+        printf("%-86s %8.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)  %s\n", name, ms, moved / ms / 1e6, moved / ms / 1e6 / 8000, check);
+        fflush(stdout);
+    };
+    auto check = [&](const char *what) -> const char * {
+        CK(hipMemset(bad, 0, 8));
+        hipLaunchKernelGGL(k_compare, dim3(4096), dim3(256), 0, 0, (const uint32_t *)dst, (const uint32_t *)ref, Z * P.dst_plane / 4, bad);
+        unsigned long long h;
+        CK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+        static char buf[96];
+        snprintf(buf, sizeof buf, h ? "MISMATCH vs A: %llu words" : "== A bit for bit", h);
+        if (h) printf("!! %s: %s\n", what, buf);
+        return buf;
+    };
+    // reference = A into `ref`
+    P.dst = ref;
+    hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P);
+    CK(hipDeviceSynchronize());
+    P.dst = dst;
+    for (int round = 0; round < (quick ? 2 : 3); ++round) {
+        printf("-- round %d\n", round);
+        double ms;
+        ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, false>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("P  plain copy, 5 planes per thread (no gains)", ms, "");
+        CK(hipMemset(dst, 0, Z * P.dst_plane));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("A  regs: gains + reciprocals in VGPRs, 5 planes per thread (shipped structure)", ms, check("A"));
+#define RUN_B(ROWS)                                                                                                       \
+    do {                                                                                                                  \
+        CK(hipMemset(dst, 0, Z *P.dst_plane));                                                                            \
+        const unsigned nb = (unsigned)(G * G * ((P.rows + ROWS - 1) / ROWS));                                             \
+        ms = time_ms([&] { hipLaunchKernelGGL((k_lds_gains<Z, ROWS>), dim3(nb), dim3(64 * Z), 0, 0, P); }, reps);         \
+        report("B  lds gains: {g, 1/g} staged in LDS per row, a wave per plane, " #ROWS " rows per workgroup", ms, check("B")); \
+    } while (0)
+        RUN_B(8);
+        if (quick) continue;
+        RUN_B(4);
+        RUN_B(2);
+        RUN_B(1);
+        RUN_B(16);
+        CK(hipMemset(dst, 0, Z * P.dst_plane));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_lds_dma<Z>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("C  lds dma: structure A, pixels by global_load_lds_dwordx4 into a per-wave ring", ms, check("C"));
+    }
+    return 0;
+}
