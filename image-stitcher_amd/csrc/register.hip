@@ -39,25 +39,74 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
 
-constexpr int MAX_LINE = 4096;     // longest line: a power of two runs in place in LDS; any other length n runs as a
-                                   // Bluestein (chirp-z) convolution through a power-of-two FFT of M >= 2n - 1 <= 8192 points
-constexpr int MAX_BLUESTEIN_M = 8192;
+// One line FFT runs in place in LDS (one line of complex128 per transform):
+//   * a power of two: radix-2 decimation in time, two stages fused per pass (lines_fft_pow2);
+//   * any other length whose prime factors are all <= 13 ("smooth": 1500 = 2^2 3 5^3, 6000 = 2^4 3 5^3, 300, 80 ...):
+//     mixed-radix Cooley-Tukey with radix 4 / 2 / 3 / 5 / 7 / 11 / 13 butterflies (lines_fft_mixed), like pocketfft --
+//     the reference's FFT -- does for such lengths;
+//   * any other length n (large prime factors: 2084 = 4 * 521, 3122 = 2 * 7 * 223, 1031): Bluestein's chirp-z form
+//     through a SMOOTH length M >= 2n - 1 (not the next power of two: 2084 -> 4200 instead of 8192 points), which is
+//     how pocketfft treats those too.
+// The longest line is what fits the 160 KB of LDS beside a few hundred bytes of reduction scratch: 9728 points, i.e.
+// any smooth crop side up to 9728 and any crop side at all up to 4860 (a 9568 x 6380 sensor gives 4784 and 3190).
+constexpr int MAX_LINE = 9728;
+constexpr int MAX_STAGES = 16;
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-inline int bluestein_m(int n) {   // 0 for a power of two (no chirp needed)
-    if (is_pow2(n)) return 0;
-    int m = 1;
-    while (m < 2 * n - 1) m <<= 1;
-    return m;
+
+// the stages of one line transform: radix[0] is the innermost (first decimation-in-time) stage
+struct AxisPlan {
+    int32_t len;                 // transform length: n, or the Bluestein length M
+    int32_t nf;                  // number of stages; 0 = power of two (the radix-2 kernel)
+    uint8_t radix[MAX_STAGES];
+};
+// true when `len` has no prime factor above 13; fills the stage list (4s first, then 2, 3, 5, 7, 11, 13)
+inline bool factor_plan(int len, AxisPlan &pl) {
+    pl = AxisPlan{};
+    pl.len = len;
+    if (len < 1) return false;
+    if (is_pow2(len)) return true;
+    int rest = len, nf = 0;
+    while (rest % 4 == 0) {
+        if (nf == MAX_STAGES) return false;
+        pl.radix[nf++] = 4;
+        rest /= 4;
+    }
+    for (int p : {2, 3, 5, 7, 11, 13})
+        while (rest % p == 0) {
+            if (nf == MAX_STAGES) return false;
+            pl.radix[nf++] = (uint8_t)p;
+            rest /= p;
+        }
+    if (rest != 1) return false;
+    pl.nf = nf;
+    return true;
 }
+inline bool is_smooth7(int v) {
+    for (int p : {2, 3, 5, 7})
+        while (v % p == 0) v /= p;
+    return v == 1;
+}
+// Bluestein length of an n-point line: 0 when n itself is smooth (no chirp needed), else the smallest 2-3-5-7-smooth
+// M >= 2n - 1; -1 when that does not fit a line
+inline int bluestein_m(int n) {
+    AxisPlan pl;
+    if (factor_plan(n, pl)) return 0;
+    for (int m = 2 * n - 1; m <= MAX_LINE; ++m)
+        if (is_smooth7(m)) return m;
+    return -1;
+}
+inline bool line_supported(int n) { return n >= 2 && n <= MAX_LINE && bluestein_m(n) >= 0; }
 inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
 
 // Workspace carve-up, identical on host (sizes) and device (pointers).
 struct Layout {
     int64_t tw0, tw1, up0, up1, spectra, amps, rowmax, d1, ccup, peak, total;
-    int64_t twm0, twm1, chirp0, chirp1, cspec0, cspec1;   // Bluestein tables per axis (unused for a power of two)
+    int64_t twm0, twm1, chirp0, chirp1, cspec0, cspec1;   // Bluestein tables per axis (unused for a smooth length)
+    int64_t perm0, perm1;        // position of frequency k in a mixed-radix line (int32 per point; unused otherwise)
     int n0, n1, n1h, region, up;
-    int m0, m1;      // Bluestein FFT length per axis, 0 = the axis length is a power of two
+    int m0, m1;      // Bluestein FFT length per axis, 0 = the axis length is smooth (transformed directly)
+    AxisPlan ax0, ax1;           // stages of the axis' transform (of length n, or of the Bluestein length m)
     int64_t per_pair_spec;
 };
 
@@ -77,8 +126,10 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     off += align16((int64_t)n0 * up * 16);
     L.up1 = off;
     off += align16((int64_t)n1 * up * 16);
-    L.m0 = bluestein_m(n0);
-    L.m1 = bluestein_m(n1);
+    L.m0 = std::max(0, bluestein_m(n0));      // (callers have checked line_supported)
+    L.m1 = std::max(0, bluestein_m(n1));
+    factor_plan(L.m0 ? L.m0 : n0, L.ax0);
+    factor_plan(L.m1 ? L.m1 : n1, L.ax1);
     L.twm0 = off;
     off += (int64_t)L.m0 * 16;
     L.twm1 = off;
@@ -91,6 +142,10 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     off += (int64_t)L.m0 * 16;
     L.cspec1 = off;
     off += (int64_t)L.m1 * 16;
+    L.perm0 = off;
+    off += (!L.m0 && L.ax0.nf) ? align16((int64_t)n0 * 4) : 0;
+    L.perm1 = off;
+    off += (!L.m1 && L.ax1.nf) ? align16((int64_t)n1 * 4) : 0;
     L.per_pair_spec = (int64_t)n0 * L.n1h * 16;
     L.spectra = off;
     off += 2 * L.per_pair_spec * n_pairs;
@@ -122,23 +177,35 @@ struct RegParams {
     int32_t n_tiles, tile_h, tile_w;
 };
 
-// tables of the Bluestein form of a line FFT (see lines_fft)
-struct Chirp {
-    int m;                 // 0: power of two, no chirp
-    const cplx *twm;       // exp(-2 pi i k / m)
-    const cplx *w;         // w[j], j < n
-    const cplx *spec;      // FFT_m of conj(w) laid out circularly
+// everything a line transform along one axis needs (see lines_fft)
+struct Axis {
+    int n;                 // data length
+    int m;                 // 0: transformed directly; else the Bluestein length
+    int ld;                // line pitch in LDS = the transform length (m ? m : n)
+    AxisPlan pl;           // stages of the transform of length ld
+    const cplx *tw;        // exp(-2 pi i k / n), k < n
+    const cplx *twm;       // exp(-2 pi i k / m)                    (Bluestein)
+    const cplx *w;         // chirp w[j] = exp(-i pi j^2 / n), j < n  (Bluestein)
+    const cplx *spec;      // FFT_m of conj(w) laid out circularly, in the order the forward m-point transform leaves it
+    const int *perm;       // mixed-radix direct transform: frequency k sits at position perm[k]; else NULL (identity)
 };
 
-__device__ __forceinline__ Chirp chirp_of(const RegParams &P, int axis) {
+__device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
     const Layout &L = P.L;
-    Chirp C;
-    C.m = axis ? L.m1 : L.m0;
-    C.twm = reinterpret_cast<const cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
-    C.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
-    C.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
-    return C;
+    Axis X;
+    X.n = axis ? L.n1 : L.n0;
+    X.m = axis ? L.m1 : L.m0;
+    X.ld = X.m ? X.m : X.n;
+    X.pl = axis ? L.ax1 : L.ax0;
+    X.tw = reinterpret_cast<const cplx *>(P.ws + (axis ? L.tw1 : L.tw0));
+    X.twm = reinterpret_cast<const cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
+    X.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
+    X.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
+    X.perm = (!X.m && X.pl.nf) ? reinterpret_cast<const int *>(P.ws + (axis ? L.perm1 : L.perm0)) : nullptr;
+    return X;
 }
+// where frequency k of a transformed line sits (and where it has to be put before the second transform)
+__device__ __forceinline__ int pos_of(const Axis &X, int k) { return X.perm ? X.perm[k] : k; }
 
 // A pair whose tile index or crop origin would read outside its tile never touches memory: its crops
 // are taken as zero and its result carries coarse = INT32_MIN (the pair table lives in device memory,
@@ -219,43 +286,163 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
     }
 }
 
-// Any other length n: Bluestein's chirp-z form of the same DFT, in place in a line of M >= 2n - 1 points (M a power
-// of two): with w[j] = exp(-i pi j^2 / n),
+// Smooth lengths: mixed-radix Cooley-Tukey in place, radices from the AxisPlan (radix[0] = the innermost stage).
+// Two forms of the same factorisation, so that no digit-reversal pass is ever needed:
+//   DIF (decimation in frequency): natural-order input  -> output in "plan order" (frequency k at position perm[k]);
+//   DIT (decimation in time):      plan-order input     -> natural-order output.
+// A forward transform runs as DIF, the transform that follows it (pointwise work happens in plan order, positions
+// looked up through perm) as DIT.  With m_s = radix[0] ... radix[s], a block of m_s points holds radix[s] sub-blocks of
+// m_(s-1) points; butterfly (block, k) takes the points {k + q m_(s-1)}, q < r:
+//   DIT: a_q = x_q W_ms^(q k),  y_j = sum_q a_q W_r^(q j);      DIF: y_j = (sum_q x_q W_r^(q j)) W_ms^(j k).
+// Twiddles come from the full-circle table tw[t] = exp(-2 pi i t / N): W_ms^e = tw[e N / m_s] (e < m_s), W_r^e = tw[e N / r].
+// float64 throughout; INV conjugates every twiddle (no 1/N anywhere, like the power-of-two kernel).
+template <bool INV>
+__device__ __forceinline__ cplx rot90(cplx a) {   // a * (-i) forward, a * (+i) inverse
+    return INV ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
+}
+template <int R, bool INV>
+__device__ __forceinline__ void small_dft(cplx (&a)[R], const cplx *__restrict__ tw, int N) {
+    if (R == 2) {
+        const cplx u = a[0], v = a[1];
+        a[0] = cadd(u, v);
+        a[1] = csub(u, v);
+    } else if (R == 4) {
+        const cplx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = rot90<INV>(csub(a[1], a[3]));
+        a[0] = cadd(t0, t2);
+        a[2] = csub(t0, t2);
+        a[1] = cadd(t1, t3);
+        a[3] = csub(t1, t3);
+    } else if (R == 3) {
+        const double S3 = 0.86602540378443864676;
+        const cplx t1 = cadd(a[1], a[2]);
+        const cplx t2 = {a[0].re - 0.5 * t1.re, a[0].im - 0.5 * t1.im};
+        const cplx d = csub(a[1], a[2]);
+        const cplx t3 = rot90<INV>(cplx{S3 * d.re, S3 * d.im});
+        a[0] = cadd(a[0], t1);
+        a[1] = cadd(t2, t3);
+        a[2] = csub(t2, t3);
+    } else if (R == 5) {
+        const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;
+        const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
+        const cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+        const cplx m1 = {a[0].re + C1 * t1.re + C2 * t2.re, a[0].im + C1 * t1.im + C2 * t2.im};
+        const cplx m2 = {a[0].re + C2 * t1.re + C1 * t2.re, a[0].im + C2 * t1.im + C1 * t2.im};
+        const cplx n1 = rot90<INV>(cplx{S1 * t3.re + S2 * t4.re, S1 * t3.im + S2 * t4.im});
+        const cplx n2 = rot90<INV>(cplx{S2 * t3.re - S1 * t4.re, S2 * t3.im - S1 * t4.im});
+        a[0] = cadd(a[0], cadd(t1, t2));
+        a[1] = cadd(m1, n1);
+        a[4] = csub(m1, n1);
+        a[2] = cadd(m2, n2);
+        a[3] = csub(m2, n2);
+    } else {   // 7, 11, 13: the plain sum with table twiddles W_R^((q j) mod R)
+        const int step = N / R;
+        cplx y[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            cplx acc = a[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) acc = cadd(acc, cmul(a[q], twiddle<INV>(tw, ((q * j) % R) * step)));
+            y[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) a[j] = y[j];
+    }
+}
+template <int R, bool INV, bool DIF>
+__device__ __forceinline__ void butterfly(cplx *x, int stride, int k, int tws, int N, const cplx *__restrict__ tw) {
+    cplx a[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) a[q] = x[q * stride];
+    if (!DIF && k) {
+#pragma unroll
+        for (int q = 1; q < R; ++q) a[q] = cmul(twiddle<INV>(tw, q * k * tws), a[q]);
+    }
+    small_dft<R, INV>(a, tw, N);
+    if (DIF && k) {
+#pragma unroll
+        for (int j = 1; j < R; ++j) a[j] = cmul(twiddle<INV>(tw, j * k * tws), a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) x[j * stride] = a[j];
+}
+// `nlines` contiguous lines of N points each; the caller has synchronised; returns synchronised
+template <bool INV, bool DIF>
+__device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
+    int m_prev = 1, m = N;
+    for (int step = 0; step < pl.nf; ++step) {
+        const int s = DIF ? pl.nf - 1 - step : step;
+        const int r = pl.radix[s];
+        if (DIF) m_prev = m / r;
+        const int nb = N / r, tws = N / (m_prev * r);
+        for (int e = tid; e < nlines * nb; e += nt) {
+            const int l = e / nb, t = e - l * nb;
+            const int blk = t / m_prev, k = t - blk * m_prev;
+            cplx *x = base + (int64_t)l * N + blk * (m_prev * r) + k;
+            switch (r) {
+                case 2: butterfly<2, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                case 3: butterfly<3, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                case 4: butterfly<4, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                case 5: butterfly<5, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                case 7: butterfly<7, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                case 11: butterfly<11, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+                default: butterfly<13, INV, DIF>(x, m_prev, k, tws, N, tw); break;
+            }
+        }
+        __syncthreads();
+        if (DIF) m = m_prev;
+        else m_prev *= r;
+    }
+}
+// one transform of length pl.len: natural -> plan order (BWD = false) or plan order -> natural (BWD = true); for a
+// power of two both orders are the natural one
+template <bool INV, bool BWD>
+__device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
+    if (!pl.nf) lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
+    else lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
+}
+
+// Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
+// M >= 2n - 1 points (M smooth): with w[j] = exp(-i pi j^2 / n),
 //     X[k] = w[k] * sum_j (x[j] w[j]) * conj(w)[k - j]
 // i.e. multiply by the chirp, convolve with the conjugate chirp (forward FFT_M, multiply by the chirp's precomputed
-// spectrum, inverse FFT_M, 1/M), multiply by the chirp again.  float64 throughout; the chirp phases are reduced
-// exactly in integers (j^2 mod 2n) before sincospi.  The inverse transform is conj(FFT(conj x)).  This is how
-// pocketfft -- the reference's FFT -- treats lengths with large prime factors too (a 6244 x 4168 sensor gives
-// crops 2084 = 4 * 521 and 3122 = 2 * 7 * 223 long); the O(n^2) direct sum of round 1 is gone.
-
-// `nlines` lines at pitch ld = (C.m ? C.m : n); data in the first n points of each line
-template <bool INV>
-__device__ void lines_fft(cplx *base, int n, int nlines, const cplx *__restrict__ tw, const Chirp &C, int tid, int nt) {
-    if (!C.m) {
-        lines_fft_pow2<INV>(base, n, nlines, tw, tid, nt);
+// spectrum -- stored in the order the forward transform leaves its output in, so nothing is permuted -- inverse FFT_M,
+// 1/M), multiply by the chirp again.  float64 throughout; the chirp phases are reduced exactly in integers
+// (j^2 mod 2n) before sincospi.  The inverse transform is conj(FFT(conj x)).  This is how pocketfft -- the
+// reference's FFT -- treats lengths with large prime factors too (a 6244 x 4168 sensor gives crops 2084 = 4 * 521 and
+// 3122 = 2 * 7 * 223 long).
+//
+// lines_fft: `nlines` lines at pitch X.ld; data in the first n points of each line.
+//   BWD = false ("first" transform): natural-order input  -> frequency k at position pos_of(X, k);
+//   BWD = true  ("second"):          input with frequency k at pos_of(X, k) -> natural-order output.
+// pos_of is the identity except for a mixed-radix direct transform.
+template <bool INV, bool BWD>
+__device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt) {
+    const int n = X.n;
+    if (!X.m) {
+        lines_fft_plan<INV, BWD>(base, nlines, X.tw, X.pl, tid, nt);
         return;
     }
-    const int M = C.m;
+    const int M = X.m;
     for (int e = tid; e < nlines * M; e += nt) {
-        const int j = e & (M - 1);
+        const int j = e % M;
         cplx v = {0.0, 0.0};
         if (j < n) {
             v = base[e];
             if (INV) v.im = -v.im;
-            v = cmul(v, C.w[j]);
+            v = cmul(v, X.w[j]);
         }
         base[e] = v;
     }
     __syncthreads();
-    lines_fft_pow2<false>(base, M, nlines, C.twm, tid, nt);
-    for (int e = tid; e < nlines * M; e += nt) base[e] = cmul(base[e], C.spec[e & (M - 1)]);
+    lines_fft_plan<false, false>(base, nlines, X.twm, X.pl, tid, nt);
+    for (int e = tid; e < nlines * M; e += nt) base[e] = cmul(base[e], X.spec[e % M]);
     __syncthreads();
-    lines_fft_pow2<true>(base, M, nlines, C.twm, tid, nt);
+    lines_fft_plan<true, true>(base, nlines, X.twm, X.pl, tid, nt);
     const double inv_m = 1.0 / (double)M;
     for (int e = tid; e < nlines * M; e += nt) {
-        const int j = e & (M - 1);
+        const int j = e % M;
         if (j < n) {
-            cplx v = cmul(base[e], C.w[j]);
+            cplx v = cmul(base[e], X.w[j]);
             v.re *= inv_m;
             v.im *= inv_m;
             if (INV) v.im = -v.im;
@@ -302,6 +489,24 @@ __global__ void init_tables_kernel(RegParams P) {
             w[j] = {cs, sn};
         }
     }
+    for (int axis = 0; axis < 2; ++axis) {   // plan-order positions of the mixed-radix direct transforms
+        const int n = axis ? L.n1 : L.n0, M = axis ? L.m1 : L.m0;
+        const AxisPlan &pl = axis ? L.ax1 : L.ax0;
+        if (M || !pl.nf) continue;
+        int *perm = reinterpret_cast<int *>(P.ws + (axis ? L.perm1 : L.perm0));
+        for (int64_t i = gid; i < n; i += stride) {
+            // i = q_nf + r_nf (q_(nf-1) + r_(nf-1) (... q_1)), the last stage's digit least significant; frequency
+            // (and, for the DIT input, sample) i sits at sum_s q_s m_(s-1), m_(s-1) = radix[0] ... radix[s-2]
+            int t = (int)i, pos = 0, m_prev = n;
+            for (int s = pl.nf - 1; s >= 0; --s) {
+                const int r = pl.radix[s];
+                m_prev /= r;
+                pos += (t % r) * m_prev;
+                t /= r;
+            }
+            perm[i] = pos;
+        }
+    }
     const int64_t m0 = (int64_t)L.n0 * L.up, m1 = (int64_t)L.n1 * L.up;
     for (int64_t j = gid; j < m0; j += stride) {
         double s, c;
@@ -315,7 +520,8 @@ __global__ void init_tables_kernel(RegParams P) {
     }
 }
 
-// spectrum of the conjugate chirp, once per axis and launch: block 0 = axis 0, block 1 = axis 1
+// spectrum of the conjugate chirp, once per axis and launch: block 0 = axis 0, block 1 = axis 1.  Left in the order
+// the forward M-point transform produces (plan order), which is the order lines_fft multiplies in.
 __global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
@@ -334,7 +540,7 @@ __global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
         x[j] = v;
     }
     __syncthreads();
-    lines_fft_pow2<false>(x, M, 1, twm, tid, nt);
+    lines_fft_plan<false, false>(x, 1, twm, axis ? L.ax1 : L.ax0, tid, nt);
     for (int j = tid; j < M; j += nt) spec[j] = x[j];
 }
 
@@ -427,7 +633,8 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
-    const int ld = L.m1 ? L.m1 : n1;               // line pitch: the Bluestein length when n1 is not a power of two
+    const Axis X = axis_of(P, 1);
+    const int ld = X.ld;                           // line pitch: the Bluestein length when n1 needs one
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
     const int pair = blockIdx.y, r0 = blockIdx.x * rl;
     const int nrow = min(rl, L.n0 - r0);
@@ -452,11 +659,11 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
         x[(int64_t)l * ld + j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     }
     __syncthreads();
-    lines_fft<false>(x, n1, nrow, reinterpret_cast<const cplx *>(P.ws + L.tw1), chirp_of(P, 1), tid, nt);
+    lines_fft<false, false>(x, X, nrow, tid, nt);
     for (int e = tid; e < nrow * n1h; e += nt) {
         const int l = e / n1h, k = e - l * n1h;
         const cplx *xl = x + (int64_t)l * ld;
-        const cplx zk = xl[k], zc = cconj(xl[k ? n1 - k : 0]);
+        const cplx zk = xl[pos_of(X, k)], zc = cconj(xl[pos_of(X, k ? n1 - k : 0)]);
         // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
         A[e] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
         const cplx d = {zk.re - zc.re, zk.im - zc.im};
@@ -494,19 +701,20 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         g[(int64_t)c * n0 + r] = B[(int64_t)r * n1h + c0 + c];
     }
     __syncthreads();
-    const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
+    const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
-        lines_fft_pow2<false>(f, n0, 2 * tc, tw0, tid, nt);
+        lines_fft<false, false>(f, X, 2 * tc, tid, nt);
     } else {
-        lines_fft_pow2<false>(f, n0, ncol, tw0, tid, nt);
-        lines_fft_pow2<false>(g, n0, ncol, tw0, tid, nt);
+        lines_fft<false, false>(f, X, ncol, tid, nt);
+        lines_fft<false, false>(g, X, ncol, tid, nt);
     }
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
     for (int c = 0; c < ncol; ++c) {
         double sf = 0.0, sg = 0.0;
         for (int r = tid; r < n0; r += nt) {
-            const cplx F = f[(int64_t)c * n0 + r], G = g[(int64_t)c * n0 + r];
+            const int at = pos_of(X, r);   // frequency r of the column (plan order until the inverse transform)
+            const cplx F = f[(int64_t)c * n0 + at], G = g[(int64_t)c * n0 + at];
             sf += F.re * F.re + F.im * F.im;
             sg += G.re * G.re + G.im * G.im;
             cplx pr = cmul(F, cconj(G));                              // skimage :211
@@ -516,7 +724,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
                 pr.re *= scl;
                 pr.im *= scl;
             }
-            f[(int64_t)c * n0 + r] = pr;
+            f[(int64_t)c * n0 + at] = pr;
         }
         for (int off = 32; off > 0; off >>= 1) {
             sf += __shfl_xor(sf, off);
@@ -541,44 +749,44 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     // the product is what the upsampled DFT reads (skimage :239): keep it in B
     for (int i = tid; i < n0 * ncol; i += nt) {
         const int r = i / ncol, c = i - r * ncol;
-        B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
+        B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + pos_of(X, r)];
     }
     __syncthreads();
-    lines_fft_pow2<true>(f, n0, ncol, tw0, tid, nt);
+    lines_fft<true, true>(f, X, ncol, tid, nt);
     for (int i = tid; i < n0 * ncol; i += nt) {
         const int r = i / ncol, c = i - r * ncol;
         A[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
     }
 }
 
-// The same for an axis-0 length that is not a power of two: one column per block, transformed in place in ONE
-// Bluestein line of m0 points (128 KB of LDS at m0 = 8192); the column spectra F and G go back to the workspace
-// between the three transforms instead of staying in LDS -- every thread re-reads exactly the elements it wrote.
-__global__ __launch_bounds__(SQ_COL_THREADS) void columns_bluestein_kernel(RegParams P) {
+// The same with ONE column per block, its line (n0 points, or the Bluestein line of m0) alone in LDS -- for an axis-0
+// length that needs Bluestein, and for direct lengths too long for two of them to share the LDS (n0 > 4608).  The
+// column spectra F and G go back to the workspace between the three transforms instead of staying in LDS -- every
+// thread re-reads exactly the elements it wrote.
+__global__ __launch_bounds__(SQ_COL_THREADS) void columns_single_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n0 = L.n0, n1h = L.n1h;
-    cplx *x = reinterpret_cast<cplx *>(smem);   // [m0]
+    cplx *x = reinterpret_cast<cplx *>(smem);   // [ld]
     __shared__ double red[2][SQ_COL_THREADS / 64];
     const int pair = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
     cplx *B = A + (int64_t)n0 * n1h;
-    const cplx *tw0 = reinterpret_cast<const cplx *>(P.ws + L.tw0);
-    const Chirp C = chirp_of(P, 0);
+    const Axis X = axis_of(P, 0);
     for (int r = tid; r < n0; r += nt) x[r] = A[(int64_t)r * n1h];
     __syncthreads();
-    lines_fft<false>(x, n0, 1, tw0, C, tid, nt);
-    for (int r = tid; r < n0; r += nt) {
-        A[(int64_t)r * n1h] = x[r];            // F, re-read below by this very thread
-        x[r] = B[(int64_t)r * n1h];
-    }
+    lines_fft<false, false>(x, X, 1, tid, nt);
+    for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[pos_of(X, r)];   // F, natural order; re-read below by this very thread
     __syncthreads();
-    lines_fft<false>(x, n0, 1, tw0, C, tid, nt);
+    for (int r = tid; r < n0; r += nt) x[r] = B[(int64_t)r * n1h];
+    __syncthreads();
+    lines_fft<false, false>(x, X, 1, tid, nt);
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double sf = 0.0, sg = 0.0;
     for (int r = tid; r < n0; r += nt) {
-        const cplx F = A[(int64_t)r * n1h], G = x[r];
+        const int at = pos_of(X, r);
+        const cplx F = A[(int64_t)r * n1h], G = x[at];
         sf += F.re * F.re + F.im * F.im;
         sg += G.re * G.re + G.im * G.im;
         cplx pr = cmul(F, cconj(G));                              // skimage :211
@@ -588,7 +796,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_bluestein_kernel(RegPa
             pr.im *= scl;
         }
         B[(int64_t)r * n1h] = pr;              // the product is what the upsampled DFT reads (skimage :239)
-        x[r] = pr;
+        x[at] = pr;
     }
     for (int off = 32; off > 0; off >>= 1) {
         sf += __shfl_xor(sf, off);
@@ -609,7 +817,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_bluestein_kernel(RegPa
         amps[0] = a;
         amps[1] = b;
     }
-    lines_fft<true>(x, n0, 1, tw0, C, tid, nt);
+    lines_fft<true, true>(x, X, 1, tid, nt);
     for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[r];
 }
 
@@ -671,7 +879,8 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
     const int nrp = (n0 + 1) / 2;
-    const int ld = L.m1 ? L.m1 : n1;
+    const Axis X = axis_of(P, 1);
+    const int ld = X.ld;
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
     const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
     const int nline = min(rl, nrp - rp0);
@@ -692,10 +901,10 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
             b = cconj(q1[n1 - k]);
         }
         if (!two) b = {0.0, 0.0};
-        x[(int64_t)l * ld + k] = {a.re - b.im, a.im + b.re};   // a + i b
+        x[(int64_t)l * ld + pos_of(X, k)] = {a.re - b.im, a.im + b.re};   // a + i b, where the second transform wants frequency k
     }
     __syncthreads();
-    lines_fft<true>(x, n1, nline, reinterpret_cast<const cplx *>(P.ws + L.tw1), chirp_of(P, 1), tid, nt);
+    lines_fft<true, true>(x, X, nline, tid, nt);
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int l = wave; l < nline; l += nw) {
         const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);
@@ -937,9 +1146,10 @@ __global__ __launch_bounds__(256) void normalize_kernel(const void *const *tile_
 
 int check_line(int n, const char *axis) {
     if (n < 2) return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %s length %d < 2", axis, n);
-    if (n > MAX_LINE)
-        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported (any length up to %d: one line, or its "
-                    "Bluestein line of up to %d points, has to fit the 160 KB of LDS)", axis, n, MAX_LINE, MAX_BLUESTEIN_M);
+    if (!line_supported(n))
+        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported: one line has to fit the 160 KB of LDS -- "
+                    "any length up to %d whose prime factors are all <= 13, any other length up to %d (its Bluestein line of "
+                    ">= 2n - 1 points)", axis, n, MAX_LINE, (MAX_LINE + 1) / 2);
     return SQ_OK;
 }
 
@@ -1004,10 +1214,15 @@ extern "C" int sq_normalize_tiles(const void *const *tile_ptrs_dev, const void *
     return SQ_OK;
 }
 
+extern "C" int sq_register_line_supported(int32_t n) { return line_supported(n) ? 1 : 0; }
+
 extern "C" int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor) {
     if (n_pairs < 0 || n0 < 2 || n1 < 2 || upsample_factor < 1 || upsample_factor > 100)
         return fail(SQ_ERR_INVALID, "sq_register_workspace_bytes: bad sizes (pairs=%d crop=%dx%d u=%d)", n_pairs, n0, n1,
                     upsample_factor);
+    int rc;
+    if ((rc = check_line(n0, "axis-0")) != SQ_OK) return rc;
+    if ((rc = check_line(n1, "axis-1")) != SQ_OK) return rc;
     return make_layout(n_pairs, n0, n1, upsample_factor).total;
 }
 
@@ -1048,9 +1263,9 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.n_tiles = a->n_tiles;
     P.tile_h = a->tile_h;
     P.tile_w = a->tile_w;
-    // columns per block (power-of-two axis 0): two [tc][n0] complex arrays in 144 KiB of LDS
-    int tc = (int)std::min<int64_t>(8, (144 * 1024) / (2 * (int64_t)L.n0 * 16));
-    if (tc < 1) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: axis-0 length %d does not fit LDS", L.n0);
+    // columns per block (directly transformed axis 0): two [tc][n0] complex arrays in 144 KiB of LDS; a longer column,
+    // or one that needs a Bluestein line, goes one per block (columns_single_kernel)
+    const int tc = L.m0 ? 0 : (int)std::min<int64_t>(8, (144 * 1024) / (2 * (int64_t)L.n0 * 16));
     P.tc = tc;
     hipStream_t s = static_cast<hipStream_t>(stream_);
 
@@ -1084,10 +1299,10 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         if ((rc = allow_lds(rows_forward_kernel<uint8_t>, lds_fwd)) != SQ_OK) return rc;
         hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
     }
-    if (L.m0) {
-        const size_t lds_col = (size_t)L.m0 * 16;
-        if ((rc = allow_lds(columns_bluestein_kernel, lds_col)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(columns_bluestein_kernel, dim3(L.n1h, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+    if (tc < 1) {
+        const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
+        if ((rc = allow_lds(columns_single_kernel, lds_col)) != SQ_OK) return rc;
+        hipLaunchKernelGGL(columns_single_kernel, dim3(L.n1h, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
     } else {
         const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
         if ((rc = allow_lds(columns_kernel, lds_col)) != SQ_OK) return rc;

@@ -17,23 +17,26 @@ import numpy as np
 from . import native, placement
 from .placement import Shifts
 
-MAX_CROP_LENGTH = 4096    # longest crop side sq_register_pairs takes (include/squidstitch.h)
+def crop_length_supported(n: int) -> bool:
+    """Whether the device pipeline takes a crop side of ``n`` pixels (include/squidstitch.h: one FFT line has to fit
+    the 160 KB of LDS -- any length up to 4860, smooth lengths up to 9720)."""
+    return bool(native.lib().sq_register_line_supported(int(n)))
 
 
 def check_crop_lengths(height: int, width: int, max_x_overlap: int, max_y_overlap: int) -> None:
-    """Raise before any work if the registration crops of a ``height x width`` tile are longer than the device
-    pipeline takes.  The reference (pocketfft) has no such limit; this one is a sensor side of ~8192 pixels."""
-    sides = [0]
+    """Raise before any work if the registration crops of a ``height x width`` tile have a side the device pipeline
+    does not take.  The reference (pocketfft) has no such limit; this one is a sensor side of ~9700 pixels."""
+    sides = []
     for make, ov in ((placement.horizontal_crop_origins, max_x_overlap), (placement.vertical_crop_origins, max_y_overlap)):
         try:
             sides.extend(make(height, width, int(ov))[:2])
         except ValueError:      # a direction with nothing to register (one row / one column): reported where it is used
             pass
-    worst = max(sides)
-    if worst > MAX_CROP_LENGTH:
-        raise ValueError(f"registration crops of a {height} x {width} tile are up to {worst} pixels long; the device "
-                         f"pipeline takes crop sides up to {MAX_CROP_LENGTH} (one FFT line has to fit the 160 KB of LDS). "
-                         "Stitch without -r, or supply h_shift / v_shift.")
+    bad = sorted({int(v) for v in sides if not crop_length_supported(v)})
+    if bad:
+        raise ValueError(f"registration crops of a {height} x {width} tile have sides of {bad} pixels; the device pipeline takes "
+                         "any crop side up to 4860 and sides with prime factors <= 13 up to 9720 (one FFT line has to fit the "
+                         "160 KB of LDS). Stitch without -r, or supply h_shift / v_shift.")
 
 
 NORMALIZATIONS = {'phase': native.SQ_NORM_PHASE, None: native.SQ_NORM_NONE, 'none': native.SQ_NORM_NONE}

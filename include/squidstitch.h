@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 103 /* 0.1.2: sq_fuse_args flags / grid_blocks, sq_basic_fit, sq_blosc_* */
+#define SQ_VERSION 104 /* 0.1.3: sq_register_line_supported (mixed-radix / smooth-Bluestein lines up to 9728 points) */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -209,12 +209,17 @@ typedef struct sq_register_args {
     int64_t workspace_bytes;
 } sq_register_args;
 
-/* Crop lengths: any n0, n1 in [2, 4096].  A power of two runs as a radix-2 FFT in LDS; every other length runs as
- * a Bluestein (chirp-z) convolution through a power-of-two LDS FFT of M >= 2n - 1 <= 8192 points, float64 like the
- * rest -- the way pocketfft (the reference's FFT, via scipy/numpy) treats lengths with large prime factors.  A
- * longer line does not fit the 160 KB of LDS: SQ_ERR_UNSUPPORTED.  (Crops are about half a tile side long,
- * stitcher.py:504-506 / :517-519, so this covers sensors up to 8192 pixels a side.)
- * Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
+/* Crop lengths.  One line of a transform (complex128) has to fit the 160 KB of LDS: 9728 points.
+ *   - a power of two: radix-2 FFT;
+ *   - any other length whose prime factors are all <= 13 (1500, 3000, 6000 ...): mixed-radix Cooley-Tukey (radix 4 / 2 / 3 /
+ *     5 / 7 / 11 / 13), directly, up to 9728 points;
+ *   - any other length n <= 4860: Bluestein's chirp-z form through a smooth length M >= 2n - 1 (2084 -> 4200 points);
+ * float64 throughout -- the factorisations pocketfft (the reference's FFT, via scipy / numpy) uses for such lengths.
+ * Anything else: SQ_ERR_UNSUPPORTED.  (Crops are about half a tile side long, stitcher.py:504-506 / :517-519: this
+ * covers every sensor up to 9720 pixels a side -- a 9568 x 6380 one gives 4784 and 3190 -- and smooth sides up to 19440.)
+ * sq_register_line_supported: 1 when a crop side of n pixels is accepted, else 0 (no device needed). */
+int sq_register_line_supported(int32_t n);
+/* Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */
 int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor);
 int sq_register_pairs(const sq_register_args *args, void *stream);
 

@@ -193,12 +193,18 @@ def pcc_vectors():
               (63, 33), (50, 47), (64, 34), (33, 128), (128, 127),   # odd widths; shifts near half the crop (wrap-around)
               # lengths with large prime factors (a 6244 x 4168 sensor: crops 2084 = 4 * 521 and 3122 = 2 * 7 * 223
               # long), a smooth one (1500), 2 * 107, primes (1031, 521), and just past a power of two (2049)
-              (2084, 214), (214, 3122), (1500, 107), (1031, 80), (96, 521), (48, 2049)]
+              (2084, 214), (214, 3122), (1500, 107), (1031, 80), (96, 521), (48, 2049),
+              # round 3: lines beyond 4096 -- smooth lengths transformed directly by mixed radix (6000 = 2^4 3 5^3, 300,
+              # 4410 = 2 3^2 5 7^2, 9720 = 2^3 3^5 5 = the longest line at all), a 9568 x 6380 sensor's crops
+              # (4784 = 2^4 13 23 and 3190 = 2 5 11 29: Bluestein through 9600 and 6400 points), and the longest
+              # Bluestein lines (4859 = 43 * 113 and 4858 = 2 * 7 * 347, both through 9720 points)
+              (6000, 300), (300, 6000), (4784, 60), (60, 3190), (4410, 52), (40, 9720), (4859, 34), (44, 4858)]
     for i, (n0, n1) in enumerate(shapes):
         seed = 4242 + i
         dy, dx = [(3, -2), (-4, 5), (0, 0), (7, 1), (-1, -6), (2, 2), (5, -3), (-2, 4),
                   (4, -3), (-5, 6), (12, -11), (-9, 14), (1, -13),
-                  (6, -9), (-7, 11), (13, 3), (-15, -4), (9, 16), (-3, -12)][i]
+                  (6, -9), (-7, 11), (13, 3), (-15, -4), (9, 16), (-3, -12),
+                  (11, -6), (-8, 14), (5, 9), (-12, -7), (15, -2), (-4, 10), (7, -15), (-10, 3)][i]
         big = synth.scene_patch(seed, 100, 100, n0 + 32, n1 + 32)      # 16-px margin: |planted| <= 16
         ref = big[16:16 + n0, 16:16 + n1]
         mov = big[16 - dy:16 - dy + n0, 16 - dx:16 - dx + n1] + synth.noise_patch(seed + 1, n0, n1, 150)

@@ -281,3 +281,42 @@ def test_config5_full_plate_96_wells_per_well_registration(tmp_path):
     stores = sum(1 for t in (0, 1) for w in wells
                  if os.path.isfile(os.path.join(tmp_path, out, f'{t}_stitched', f'{w}_stitched.ome.zarr', '.zattrs')))
     assert stores == 192
+
+
+def test_config5_one_well_at_real_tile_size(tmp_path):
+    """BASELINE config 5 at its REAL tile size: two wells of 5 x 5 tiles of 2048 x 2048 pixels x 3
+    channels, T = 2 (300 files, 2.5 GB, written from the device generator), through the CLI with ``-r
+    --per-region-registration`` exactly like the plate run.  Every (timepoint, well) unit's shifts and level-0 voxels equal
+    the oracle's (the store read through the independent spec-level reader); the pyramid of one unit equals the oracle's."""
+    import json
+    import torch
+    import blosc_ref
+    spec = synth.GridSpec(rows=5, cols=5, tile_h=2048, tile_w=2048, ov_y=244, ov_x=244, jy=3, jx=-2, seed=5200, regions=('C4', 'F11'),
+                          nt=2, channels=synth.DEFAULT_CHANNELS[:3])
+    root = str(tmp_path / 'wells')
+    paths = synth.write_acquisition_device(spec, root, torch.device('cuda:0'))
+    assert len(paths) == 2 * 2 * 25 * 3
+    from image_stitcher_amd import stitcher_cli
+    stitcher_cli.main(['-i', root, '-r', '--per-region-registration'])
+    (out,) = [d for d in os.listdir(tmp_path) if d.startswith('wells_stitched_')]
+    with open(os.path.join(tmp_path, out, 'shift_table.json')) as fh:
+        table = json.load(fh)
+    assert table['per_region_registration'] is True
+    assert [(e['timepoint'], e['region']) for e in table['shifts']] == [(0, 'C4'), (0, 'F11'), (1, 'C4'), (1, 'F11')]
+    acq = O.parse_acquisition(root, read_image)
+    for e in table['shifts']:
+        t, well = e['timepoint'], e['region']
+        want_s = O.calculate_shifts(acq, t, well, read_image, '', 0, 'Unidirectional', 'phase')
+        assert (tuple(e['h_shift']), tuple(e['v_shift'])) == (tuple(want_s['h_shift']), tuple(want_s['v_shift'])) == ((3, -244), (-244, -2))
+        want = O.stitch_region(acq, t, well, read_image, True, want_s)
+        assert want.shape[1:3] == (3, 1) and want.shape[3] > 9000 and want.shape[4] > 9000
+        store = os.path.join(tmp_path, out, f'{t}_stitched', f'{well}_stitched.ome.zarr')
+        got, meta, _ = blosc_ref.read_zarr_v2_array(os.path.join(store, '0'))
+        np.testing.assert_array_equal(got, want)
+        assert meta['compressor']['id'] == 'blosc'
+        if (t, well) == (1, 'F11'):
+            levels = O.pyramid_nearest(want, len([d for d in os.listdir(store) if d.isdigit()]))
+            assert len(levels) >= 4
+            for lv, wl in enumerate(levels):
+                np.testing.assert_array_equal(blosc_ref.read_zarr_v2_array(os.path.join(store, str(lv)))[0], wl)
+        del want, got

@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sq_version() == 103
+    assert L.sq_version() == 104
 
 
 def test_struct_layouts_match_header():
@@ -247,3 +247,23 @@ def test_wide_span_column_cuts_leave_no_sliver():
     assert widths == [116, 1984] and all((it['hw'] >> 16) == 8 for it in items)
     seams = decode_seams(plan)
     assert sorted(int(f) for f in seams['flags']) == [HAS_LEFT, HAS_LEFT, LEAVE_TAIL, LEAVE_TAIL]
+
+
+def test_register_line_lengths_supported_without_a_device():
+    """include/squidstitch.h: a crop side is taken when its line fits the LDS -- a length whose prime factors are all
+    <= 13 up to 9728 points (largest such: 9720), any other length through a smooth Bluestein line of >= 2n - 1 points
+    (so up to 4860).  The reference (pocketfft) takes any length; the binding reports the limit up front."""
+    from image_stitcher_amd import registration
+    L = native.lib()
+    ok = [2, 3, 7, 13, 64, 80, 214, 521, 1024, 1031, 1500, 2084, 3122, 3190, 3989, 4096, 4784, 4858, 4859, 4860, 6000, 8192, 9600, 9720]
+    bad = [0, 1, -5, 4861, 4862, 4863, 5003, 9721, 9728, 9733, 10000, 16384]
+    assert [n for n in ok if not L.sq_register_line_supported(n)] == []
+    assert [n for n in bad if L.sq_register_line_supported(n)] == []
+    assert registration.crop_length_supported(6000) and not registration.crop_length_supported(4861)
+    # crops are tile/2 long (stitcher.py:504-506): a 9568 x 6380 sensor passes, a 9722-pixel side (crop 9722 - 2 * 2430 = 4862 = 2 * 11 * 13 * 17) does not
+    registration.check_crop_lengths(6380, 9568, 256, 256)
+    registration.check_crop_lengths(12000, 12000, 300, 300)
+    with pytest.raises(ValueError, match='4862'):
+        registration.check_crop_lengths(9722, 2048, 256, 256)
+    assert L.sq_register_workspace_bytes(4, 6000, 300, 10) > 0
+    assert L.sq_register_workspace_bytes(4, 4861, 300, 10) < 0 and b'not supported' in L.sq_last_error()

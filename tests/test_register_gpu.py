@@ -95,7 +95,9 @@ def test_bad_arguments():
     with pytest.raises(ValueError, match='normalization'):
         registration.phase_cross_correlation(a, a, normalization='bogus')
     with pytest.raises(native.NativeError, match='not supported'):     # one line (or its Bluestein line) must fit LDS
-        registration.phase_cross_correlation(np.zeros((16, 4097), np.uint16), np.zeros((16, 4097), np.uint16))
+        registration.phase_cross_correlation(np.zeros((16, 4861), np.uint16), np.zeros((16, 4861), np.uint16))   # prime: 9721+ points
+    with pytest.raises(native.NativeError, match='not supported'):
+        registration.phase_cross_correlation(np.zeros((9728, 16), np.uint16), np.zeros((9728, 16), np.uint16))   # 2^9 * 19
 
 
 def test_tile_minmax_and_normalised_crops_via_grid_center():
@@ -159,12 +161,15 @@ def test_config2_crop_shape_1024x256_and_all_pairs_batch():
 
 
 def test_long_non_power_of_two_lines():
-    """Any crop length up to 4096 (Bluestein through the power-of-two LDS FFT): 3000 x 3000 sensors give
-    1500-long crops, 6244 x 4168 ones 2084 / 3122, and the longest lines at all (4095, 4096, 2049 = just past a
-    power of two, 3989 prime) on either axis: same shifts as the oracle."""
+    """Any crop length up to 4860, smooth ones up to 9720: 3000 x 3000 sensors give 1500-long crops (mixed radix),
+    6244 x 4168 ones 2084 / 3122 (Bluestein through 4200 / 6250 points), 9568 x 6380 ones 4784 / 3190; 4095, 4096,
+    2049 = just past a power of two, 3989 prime; radix-7 / 11 / 13 stages (2002 = 2 7 11 13, 1001); lines beyond
+    4096 transformed directly (6000, 8192, 9720) and through Bluestein (4859 -> 9720 points) on either axis: same
+    shifts as the oracle."""
     rng = np.random.default_rng(4)
     for n0, n1 in ((1500, 48), (48, 1500), (750, 100), (2084, 214), (218, 3122), (4095, 24), (24, 4095), (4096, 30),
-                   (30, 2049), (3989, 20), (20, 3989), (521, 521)):
+                   (30, 2049), (3989, 20), (20, 3989), (521, 521), (2002, 26), (26, 1001), (6000, 20), (20, 6000),
+                   (8192, 16), (16, 9720), (4859, 20), (20, 4784), (3190, 18), (4608, 40), (4620, 40)):
         big = synth.scene_patch(77, 0, 0, n0 + 64, n1 + 64)
         dy, dx = 7, -5
         ref = big[32:32 + n0, 32:32 + n1].astype(np.uint16)

@@ -382,6 +382,33 @@ int main(int argc, char **argv) {
         if (h) printf("!! %s: %s\n", what, buf);
         return buf;
     };
+    if (argc > 5 && atoi(argv[5])) {
+        // PLACEMENT experiment: same sizes, same kernel, fresh allocations in one process.  trial t re-allocates the canvas
+        // (odd t) or the tile stacks (even t > 0); earlier allocations stay alive so that new memory is handed out
+        printf("placement: kernel A on fresh allocations (sizes fixed); pointers modulo 2 MiB / 1 GiB in brackets\n");
+        for (int trial = 0; trial < atoi(argv[5]); ++trial) {
+            if (trial > 0 && (trial & 1)) {
+                char *nd;
+                CK(hipMalloc(&nd, Z * P.dst_plane));
+                dst = nd;
+            } else if (trial > 0) {
+                char *ns;
+                CK(hipMalloc(&ns, Z * P.src_plane));
+                CK(hipMemcpy(ns, src, Z * P.src_plane, hipMemcpyDeviceToDevice));
+                src = ns;
+            }
+            P.src = src;
+            P.dst = dst;
+            const double ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+            const double msp = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, false>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+            printf("trial %d (%s): tiles %p [%zu KiB, %zu MiB]  canvas %p [%zu KiB, %zu MiB]   A %.3f   P %.3f of 8 TB/s\n", trial,
+                   trial == 0 ? "first" : ((trial & 1) ? "new canvas" : "new tiles"), (void *)src, ((uintptr_t)src & ((2u << 20) - 1)) >> 10,
+                   ((uintptr_t)src & ((1u << 30) - 1)) >> 20, (void *)dst, ((uintptr_t)dst & ((2u << 20) - 1)) >> 10,
+                   ((uintptr_t)dst & ((1u << 30) - 1)) >> 20, moved / ms / 1e6 / 8000, moved / msp / 1e6 / 8000);
+            fflush(stdout);
+        }
+        return 0;
+    }
     // reference = A into `ref`
     P.dst = ref;
     hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P);
