@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -27,6 +28,21 @@ std::string &last_error_ref() {
 using namespace sq;
 
 namespace {
+
+// fn(t, lo, hi) over [0, n) cut into `nthreads` contiguous ranges; thread 0 is the caller
+template <typename F>
+void parallel_ranges(int nthreads, size_t n, F fn) {
+    if (nthreads <= 1 || n == 0) {
+        fn(0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads - 1);
+    auto bound = [&](int t) { return n * (size_t)t / (size_t)nthreads; };
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back([&, t] { fn(t, bound(t), bound(t + 1)); });
+    fn(0, bound(0), bound(1));
+    for (auto &th : pool) th.join();
+}
 
 struct Clipped {
     int y0, y1, x0, x1;  // canvas extent [y0,y1) x [x0,x1)
@@ -308,63 +324,95 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     // Overwrite plans cut rows on the canvas' own grid of BLOCK_ROWS rows (not from the top of each span), so that
     // the items either side of a vertical seam cover the same rows and the seam can be given one owner (Seam in
     // common.h); a column remainder narrower than a line is widened at the expense of the piece before it.
-    std::vector<Item> items;
-    {   // exact count first: a 32x32 grid has 2 172 spans but 303 744 items, and growing a 10 MB vector by doubling
-        // cost more than generating the items
-        size_t n = 0;
-        for (const Span &sp : spans) {
-            const bool ow = mode == SQ_FUSE_OVERWRITE;
-            const int item_rows = (!ow && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
-            const int64_t row_steps = ow ? ((int64_t)(sp.dst_y + sp.h - 1) / item_rows - sp.dst_y / item_rows + 1)
-                                         : ((int64_t)sp.h + item_rows - 1) / item_rows;
-            n += (size_t)(row_steps * (((int64_t)sp.w + BLOCK_COLS - 1) / BLOCK_COLS + 1));   // +1: a widened remainder
+    // Items are generated span by span; a 32x32 grid has 2 172 spans but 303 744 items, so the spans' item counts are
+    // worked out first (the same cutting rules, counted) and the spans then filled in by a few threads, each span
+    // straight into its final range of the list -- the list is the one a single thread would produce.
+    const bool ow_mode = mode == SQ_FUSE_OVERWRITE;
+    auto rows_of = [&](const Span &sp) { return (!ow_mode && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS; };
+    auto col_pieces = [&](const Span &sp) {
+        int n = 0;
+        for (int c0 = 0; c0 < sp.w; ++n) {
+            int cols = std::min(BLOCK_COLS, sp.w - c0);
+            const int rest = sp.w - c0 - cols;
+            if (ow_mode && rest > 0 && rest < SEAM_MIN_COLS) cols -= SEAM_MIN_COLS;
+            c0 += cols;
         }
-        items.reserve(n);
-    }
+        return n;
+    };
+    std::vector<size_t> span_first(spans.size() + 1, 0);
     for (size_t so = 0; so < spans.size(); ++so) {
-        const size_t si = span_order[so];
-        const Span &sp = spans[si];
-        const bool ow = mode == SQ_FUSE_OVERWRITE;
-        const Ref *rf = (ow && sp.nref) ? &refs[sp.ref0] : nullptr;
-        // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
-        // workgroup (fuse.hip blend_item): taller items there, two pairs per thread on a 244-pixel strip
-        const int item_rows = (!ow && sp.nref >= 2) ? FEATHER_BLEND_ROWS : BLOCK_ROWS;
-        for (int r0 = 0; r0 < sp.h;) {
-            const int rows = std::min(ow ? item_rows - (sp.dst_y + r0) % item_rows : item_rows, sp.h - r0);
-            for (int c0 = 0; c0 < sp.w;) {
-                int cols = std::min(BLOCK_COLS, sp.w - c0);
-                const int rest = sp.w - c0 - cols;
-                if (ow && rest > 0 && rest < SEAM_MIN_COLS) cols -= SEAM_MIN_COLS;
-                Item it;
-                it.dst_y = sp.dst_y + r0;
-                it.dst_x = sp.dst_x + c0;
-                it.hw = (rows << 16) | cols;
-                it.nref = sp.nref;
-                it.span = (int32_t)si;
-                if (ow) {
-                    it.a = rf ? rf->tile : -1;
-                    it.b = rf ? rf->src_y + r0 : 0;
-                    it.c = rf ? rf->src_x + c0 : 0;
-                } else {
-                    it.a = sp.ref0;
-                    it.b = r0;
-                    it.c = c0;
-                }
-                items.push_back(it);
-                c0 += cols;
-            }
-            r0 += rows;
-        }
+        const Span &sp = spans[span_order[so]];
+        const int item_rows = rows_of(sp);
+        const int64_t row_steps = sp.h <= 0 ? 0
+                                  : (ow_mode ? ((int64_t)(sp.dst_y + sp.h - 1) / item_rows - sp.dst_y / item_rows + 1)
+                                             : ((int64_t)sp.h + item_rows - 1) / item_rows);
+        span_first[so + 1] = span_first[so] + (size_t)(row_steps * col_pieces(sp));
     }
+    // The big work lists live in per-thread scratch that keeps its capacity between calls: a 32x32 plan needs ~30 MB
+    // of them, and fresh pages for that (mmap, first touch, munmap) cost more than filling them.
+    // (the worker threads below must see THIS thread's lists: plain references, not the thread_local names)
+    static thread_local std::vector<Item> items_tls;
+    static thread_local std::vector<Seam> seams_tls;
+    static thread_local std::vector<int32_t> by_band_tls;
+    std::vector<Item> &items = items_tls;
+    std::vector<Seam> &seams = seams_tls;
+    std::vector<int32_t> &by_band = by_band_tls;
+    items.resize(span_first.back());
+    const int hw_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+#ifdef SQ_EXPERIMENTS
+    const char *threads_env = getenv("SQ_PLAN_THREADS");
+    const int nthreads = threads_env ? std::max(1, atoi(threads_env)) : (items.size() >= 32768 ? hw_threads : 1);
+#else
+    const int nthreads = items.size() >= 32768 ? hw_threads : 1;
+#endif
+    parallel_ranges(nthreads, spans.size(), [&](int, size_t so_lo, size_t so_hi) {
+        for (size_t so = so_lo; so < so_hi; ++so) {
+            const size_t si = span_order[so];
+            const Span &sp = spans[si];
+            const bool ow = ow_mode;
+            const Ref *rf = (ow && sp.nref) ? &refs[sp.ref0] : nullptr;
+            // feather: spans that several tiles cover are blended (row, 8-pixel group) pair by pair by all threads of a
+            // workgroup (fuse.hip blend_item): taller items there, two pairs per thread on a 244-pixel strip
+            const int item_rows = rows_of(sp);
+            Item *out = items.data() + span_first[so];
+            for (int r0 = 0; r0 < sp.h;) {
+                const int rows = std::min(ow ? item_rows - (sp.dst_y + r0) % item_rows : item_rows, sp.h - r0);
+                for (int c0 = 0; c0 < sp.w;) {
+                    int cols = std::min(BLOCK_COLS, sp.w - c0);
+                    const int rest = sp.w - c0 - cols;
+                    if (ow && rest > 0 && rest < SEAM_MIN_COLS) cols -= SEAM_MIN_COLS;
+                    Item it;
+                    it.dst_y = sp.dst_y + r0;
+                    it.dst_x = sp.dst_x + c0;
+                    it.hw = (rows << 16) | cols;
+                    it.nref = sp.nref;
+                    it.span = (int32_t)si;
+                    if (ow) {
+                        it.a = rf ? rf->tile : -1;
+                        it.b = rf ? rf->src_y + r0 : 0;
+                        it.c = rf ? rf->src_x + c0 : 0;
+                    } else {
+                        it.a = sp.ref0;
+                        it.b = r0;
+                        it.c = c0;
+                    }
+                    *out++ = it;
+                    c0 += cols;
+                }
+                r0 += rows;
+            }
+        }
+    });
     const int64_t n_items = (int64_t)items.size();
 
     // seam owners: item J takes the seam on its left when the item I that ends where J begins covers the same rows
     // and both are at least a line wide (tile or zero fill, either side)
-    std::vector<Seam> seams;
+    seams.clear();
     if (mode == SQ_FUSE_OVERWRITE) {
         seams.assign(items.size(), Seam{-1, 0, 0, 0});
         const int nb = canvas_h / BLOCK_ROWS + 1;
-        std::vector<int32_t> first(nb + 1, 0), by_band(items.size());
+        std::vector<int32_t> first(nb + 1, 0);
+        by_band.resize(items.size());
         for (const Item &it : items) ++first[it.dst_y / BLOCK_ROWS + 1];
         for (int k = 0; k < nb; ++k) first[k + 1] += first[k];
         {
@@ -374,26 +422,32 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         // inside a band: by (first row, END column), so that the item ending where J begins is a binary search away
         // (a 100 x 100 grid has 100+ items per band and millions of items)
         auto end_key = [&](int32_t i) { return ((int64_t)items[i].dst_y << 32) | (uint32_t)(items[i].dst_x + (items[i].hw & 0xFFFF)); };
-        for (int k = 0; k < nb; ++k)
-            std::sort(by_band.begin() + first[k], by_band.begin() + first[k + 1],
-                      [&](int32_t a, int32_t b) { return end_key(a) < end_key(b); });
-        for (size_t j = 0; j < items.size(); ++j) {
-            const Item &J = items[j];
-            if ((J.hw & 0xFFFF) < SEAM_MIN_COLS || J.dst_x == 0) continue;
-            const int k = J.dst_y / BLOCK_ROWS;
-            const int64_t want = ((int64_t)J.dst_y << 32) | (uint32_t)J.dst_x;
-            auto lo = std::lower_bound(by_band.begin() + first[k], by_band.begin() + first[k + 1], want,
-                                       [&](int32_t a, int64_t key) { return end_key(a) < key; });
-            if (lo == by_band.begin() + first[k + 1] || end_key(*lo) != want) continue;
-            const Item &I = items[*lo];      // the canvas is partitioned: at most one item ends at (row, column)
-            const int in = I.hw & 0xFFFF;
-            if ((I.hw >> 16) != (J.hw >> 16) || in < SEAM_MIN_COLS) continue;
-            seams[j].a = I.a;
-            seams[j].b = I.b;
-            seams[j].c = I.c + in;
-            seams[j].flags |= SEAM_HAS_LEFT | (I.nref ? 0 : SEAM_LEFT_ZERO);
-            seams[*lo].flags |= SEAM_LEAVE_TAIL;
-        }
+        parallel_ranges(nthreads, (size_t)nb, [&](int, size_t k_lo, size_t k_hi) {
+            for (size_t k = k_lo; k < k_hi; ++k)
+                std::sort(by_band.begin() + first[k], by_band.begin() + first[k + 1],
+                          [&](int32_t a, int32_t b) { return end_key(a) < end_key(b); });
+        });
+        // J's record is written by the thread that owns j; the LEAVE_TAIL bit of its left neighbour I belongs to another
+        // item's record (which its own thread may be flagging HAS_LEFT at this moment): both go in with atomic ORs
+        parallel_ranges(nthreads, items.size(), [&](int, size_t j_lo, size_t j_hi) {
+            for (size_t j = j_lo; j < j_hi; ++j) {
+                const Item &J = items[j];
+                if ((J.hw & 0xFFFF) < SEAM_MIN_COLS || J.dst_x == 0) continue;
+                const int k = J.dst_y / BLOCK_ROWS;
+                const int64_t want = ((int64_t)J.dst_y << 32) | (uint32_t)J.dst_x;
+                auto lo = std::lower_bound(by_band.begin() + first[k], by_band.begin() + first[k + 1], want,
+                                           [&](int32_t a, int64_t key) { return end_key(a) < key; });
+                if (lo == by_band.begin() + first[k + 1] || end_key(*lo) != want) continue;
+                const Item &I = items[*lo];      // the canvas is partitioned: at most one item ends at (row, column)
+                const int in = I.hw & 0xFFFF;
+                if ((I.hw >> 16) != (J.hw >> 16) || in < SEAM_MIN_COLS) continue;
+                seams[j].a = I.a;
+                seams[j].b = I.b;
+                seams[j].c = I.c + in;
+                __atomic_fetch_or(&seams[j].flags, SEAM_HAS_LEFT | (I.nref ? 0 : SEAM_LEFT_ZERO), __ATOMIC_RELAXED);
+                __atomic_fetch_or(&seams[*lo].flags, SEAM_LEAVE_TAIL, __ATOMIC_RELAXED);
+            }
+        });
     }
 
     auto key_of = [&](const Item &it) {
@@ -403,8 +457,21 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         if (order_mode == 5 && !it.nref) return (it.dst_y / BLOCK_ROWS) % (nblk - 1);
         return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1;
     };
+    const bool bucketed = order_mode == 1 || order_mode == 2 || order_mode == 4 || order_mode == 5;
+    // bucket sizes, kept per thread range: the k-th item of a bucket (in list order) then knows its rank without a
+    // serial pass -- rank = items of the bucket in earlier ranges + its rank inside its own range
+    std::vector<std::vector<int64_t>> hist(nthreads, std::vector<int64_t>(nblk, 0));
+    parallel_ranges(nthreads, items.size(), [&](int t, size_t lo, size_t hi) {
+        std::vector<int64_t> &h = hist[t];
+        for (size_t i = lo; i < hi; ++i) ++h[bucketed ? key_of(items[i]) : 0];
+    });
     std::vector<int64_t> count(nblk, 0);
-    for (const Item &it : items) ++count[(order_mode == 1 || order_mode == 2 || order_mode == 4 || order_mode == 5) ? key_of(it) : 0];
+    for (int t = 0; t < nthreads; ++t)
+        for (int k = 0; k < nblk; ++k) {
+            const int64_t c = hist[t][k];
+            hist[t][k] = count[k];      // -> rank of the range's first item of bucket k
+            count[k] += c;
+        }
     const auto t_items = std::chrono::steady_clock::now();
 
     auto *plan = new sq_fuse_plan;
@@ -474,28 +541,30 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             hd.lane_items = common;
             std::memcpy(plan->table.ptr, &hd, sizeof hd);
         }
-        std::vector<int64_t> seen(nblk, 0);
-        for (size_t i = 0; i < items.size(); ++i) {
-            const int k = key_of(items[i]);
-            const int64_t j = seen[k]++;
-            int64_t pos;
-            if (k == nblk - 1 || order_mode == 1) {
-                pos = start[k] + j;
-            } else {
-                const int x = k % NX;
-                const int64_t t = lane_base[k] + j;
-                pos = t < common ? t * NX + x : tail_at[x] + (t - common);
+        parallel_ranges(nthreads, items.size(), [&](int th, size_t lo, size_t hi) {
+            std::vector<int64_t> seen = hist[th];
+            for (size_t i = lo; i < hi; ++i) {
+                const int k = key_of(items[i]);
+                const int64_t j = seen[k]++;
+                int64_t pos;
+                if (k == nblk - 1 || order_mode == 1) {
+                    pos = start[k] + j;
+                } else {
+                    const int x = k % NX;
+                    const int64_t t = lane_base[k] + j;
+                    pos = t < common ? t * NX + x : tail_at[x] + (t - common);
+                }
+                place(pos, i);
             }
-            place(pos, i);
-        }
+        });
     }
     const auto t_order = std::chrono::steady_clock::now();
     const size_t n_spans_dbg = spans.size();
 #ifdef SQ_EXPERIMENTS
     if (getenv("SQ_PLAN_TIMING")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[plan] sweep %.3f ms, count %.3f ms, emit %.3f ms (%zu spans, %lld items)\n",
-                ms(t_begin, t_sweep), ms(t_sweep, t_items), ms(t_items, t_order), n_spans_dbg, (long long)n_items);
+        fprintf(stderr, "[plan] sweep %.3f ms, items + seams %.3f ms, emit %.3f ms (%zu spans, %lld items, %d threads)\n",
+                ms(t_begin, t_sweep), ms(t_sweep, t_items), ms(t_items, t_order), n_spans_dbg, (long long)n_items, nthreads);
     }
 #else
     (void)t_begin; (void)t_sweep; (void)t_items; (void)t_order; (void)n_spans_dbg;

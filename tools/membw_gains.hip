@@ -282,6 +282,66 @@ __global__ __launch_bounds__(256) void k_lds_dma(const Geo P) {
     }
 }
 
+// yardsticks for the placement experiment: a linear copy and a linear fill of the same byte count
+__global__ __launch_bounds__(256) void k_linear_copy(const u32x4 *src, u32x4 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(((const G1 u32x4 *)src)[i], (G1 u32x4 *)dst + i);
+}
+__global__ __launch_bounds__(256) void k_linear_fill(u32x4 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32x4 v = {1u, 2u, 3u, 4u};
+    if (i < n) __builtin_nontemporal_store(v, (G1 u32x4 *)dst + i);
+}
+// canvas rows only: zero fill of the same row segments (no source at all)
+template <int Z>
+__global__ __launch_bounds__(256) void k_fill_rows(const Geo P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    const u32x4 v = {1u, 2u, 3u, 4u};
+    for (int j = 0; j < 2; ++j) {
+        const int r = blk * 8 + wave + 4 * j;
+        if (r >= P.rows) break;
+        const RowAddr A = row_of(P, tile, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k - A.shift;
+            if (i >= 0 && i < nvec)
+#pragma unroll
+                for (int z = 0; z < Z; ++z) st_nt(A.d + z * P.dst_plane + (uint32_t)i * 16u, v);
+        }
+    }
+}
+
+// per-plane canvas pointers (each plane its own allocation): the row fill and the plain 5-planes-per-thread copy
+struct PlanePtrs { char *d[ZMAX]; };
+template <int Z, bool COPY>
+__global__ __launch_bounds__(256) void k_rows_pp(const Geo P, const PlanePtrs D) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    for (int j = 0; j < 2; ++j) {
+        const int r = blk * 8 + wave + 4 * j;
+        if (r >= P.rows) break;
+        const RowAddr A = row_of(P, tile, r);      // A.d relative to P.dst = nullptr: an offset
+        const size_t doff = (size_t)(A.d - P.dst);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k - A.shift;
+            const bool act = i >= 0 && i < nvec;
+            const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+            u32x4 px[Z];
+#pragma unroll
+            for (int z = 0; z < Z; ++z) px[z] = COPY ? ((const G1 U4U *)(A.s + z * P.src_plane + o))->v : u32x4{1u, 2u, 3u, 4u};
+#pragma unroll
+            for (int z = 0; z < Z; ++z)
+                if (act) st_nt(D.d[z] + doff + o, px[z]);
+        }
+    }
+}
+
 __global__ void k_compare(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *bad) {
     unsigned long long mine = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += a[i] != b[i];
@@ -382,6 +442,56 @@ int main(int argc, char **argv) {
         if (h) printf("!! %s: %s\n", what, buf);
         return buf;
     };
+    if (argc > 5 && atoi(argv[5]) == 100) {
+        // PER-PLANE ALLOCATIONS: every canvas plane its own hipMalloc (2 MiB-aligned base, so the row phases inside a
+        // 128-byte line are those of the single allocation), a few sets per process, with and without spacer
+        // allocations of odd sizes in between
+        P.src = src;
+        P.dst = nullptr;
+        size_t sp = 0;
+        for (int set = 0; set < 8; ++set) {
+            PlanePtrs D;
+            for (int z = 0; z < Z; ++z) {
+                if (set >= 4) {   // a spacer of a different size before every plane
+                    char *spacer;
+                    sp = sp * 1103515245u + 12345u;
+                    CK(hipMalloc(&spacer, ((sp >> 8) % 997 + 3) << 20));
+                }
+                CK(hipMalloc(&D.d[z], P.dst_plane));
+            }
+            const double msr = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            const double msc = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, true>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            printf("set %d (%s): planes at %p %p %p %p %p   row fill %.3f   copy 5 planes/thread %.3f of 8 TB/s\n", set, set >= 4 ? "spacers" : "back to back",
+                   (void *)D.d[0], (void *)D.d[1], (void *)D.d[2], (void *)D.d[3], (void *)D.d[4], 0.5 * moved / msr / 1e6 / 8000, moved / msc / 1e6 / 8000);
+            fflush(stdout);
+        }
+        return 0;
+    }
+    if (argc > 5 && atoi(argv[5]) < 0) {
+        // STRIDE-IN-ONE-ALLOCATION experiment: one canvas allocation with slack; the row fill (the pattern that shows the
+        // effect most: 0.56 / 0.73) and kernel A against the byte distance between consecutive canvas planes
+        const size_t slack = (size_t)320 << 20;
+        const int nalloc = -atoi(argv[5]);
+        for (int a = 0; a < nalloc; ++a) {
+            char *big;
+            CK(hipMalloc(&big, Z * (P.dst_plane + slack)));
+            P.src = src;
+            P.dst = big;
+            printf("allocation %d: canvas %p\n", a, (void *)big);
+            const size_t pads[] = {0, 256, 512, 1024, 4096, 16384, 65536, 65536 + 256, 1 << 20, (1 << 20) + 4352, 2 << 20, 4 << 20, 16 << 20, (16 << 20) + 65792,
+                                   64 << 20, (64 << 20) + 256, 128 << 20, 256 << 20, (256 << 20) + (1 << 20) + 4352, 317 << 20};
+            const size_t base_plane = P.dst_plane;
+            for (size_t pad : pads) {
+                P.dst_plane = base_plane + pad;
+                const double msr = time_ms([&] { hipLaunchKernelGGL((k_fill_rows<Z>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+                const double ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+                printf("  canvas plane stride %zu (+%zu): row fill %.3f   A %.3f of 8 TB/s\n", P.dst_plane, pad, 0.5 * moved / msr / 1e6 / 8000, moved / ms / 1e6 / 8000);
+                fflush(stdout);
+            }
+            P.dst_plane = base_plane;
+        }
+        return 0;
+    }
     if (argc > 5 && atoi(argv[5])) {
         // PLACEMENT experiment: same sizes, same kernel, fresh allocations in one process.  trial t re-allocates the canvas
         // (odd t) or the tile stacks (even t > 0); earlier allocations stay alive so that new memory is handed out
@@ -401,10 +511,23 @@ int main(int argc, char **argv) {
             P.dst = dst;
             const double ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
             const double msp = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, false>), dim3(items8), dim3(256), 0, 0, P); }, reps);
-            printf("trial %d (%s): tiles %p [%zu KiB, %zu MiB]  canvas %p [%zu KiB, %zu MiB]   A %.3f   P %.3f of 8 TB/s\n", trial,
-                   trial == 0 ? "first" : ((trial & 1) ? "new canvas" : "new tiles"), (void *)src, ((uintptr_t)src & ((2u << 20) - 1)) >> 10,
-                   ((uintptr_t)src & ((1u << 30) - 1)) >> 20, (void *)dst, ((uintptr_t)dst & ((2u << 20) - 1)) >> 10,
-                   ((uintptr_t)dst & ((1u << 30) - 1)) >> 20, moved / ms / 1e6 / 8000, moved / msp / 1e6 / 8000);
+            // one plane per launch (the per-plane kernel's pattern), five launches
+            const double ms1 = time_ms([&] {
+                for (int z = 0; z < Z; ++z) {
+                    Geo Q = P;
+                    Q.src = P.src + z * P.src_plane;
+                    Q.dst = P.dst + z * P.dst_plane;
+                    hipLaunchKernelGGL((k_regs<1, false>), dim3(items8), dim3(256), 0, 0, Q);
+                }
+            }, reps);
+            const size_t nlin = Z * P.dst_plane / 16;
+            const double msl = time_ms([&] { hipLaunchKernelGGL(k_linear_copy, dim3((unsigned)((nlin + 255) / 256)), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)dst, nlin); }, reps);
+            const double msf = time_ms([&] { hipLaunchKernelGGL(k_linear_fill, dim3((unsigned)((nlin + 255) / 256)), dim3(256), 0, 0, (u32x4 *)dst, nlin); }, reps);
+            const double msr = time_ms([&] { hipLaunchKernelGGL((k_fill_rows<Z>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+            printf("trial %d (%s): canvas %p [%4zu MiB in its GiB]  A %.3f  P(5 planes/thread) %.3f  P(1 plane/launch) %.3f  row fill %.3f | linear copy %.3f  linear fill %.3f of 8 TB/s\n",
+                   trial, trial == 0 ? "first" : ((trial & 1) ? "new canvas" : "new tiles"), (void *)dst, ((uintptr_t)dst & ((1u << 30) - 1)) >> 20,
+                   moved / ms / 1e6 / 8000, moved / msp / 1e6 / 8000, moved / ms1 / 1e6 / 8000, 0.5 * moved / msr / 1e6 / 8000,
+                   2.0 * nlin * 16 / msl / 1e6 / 8000, 1.0 * nlin * 16 / msf / 1e6 / 8000);
             fflush(stdout);
         }
         return 0;
