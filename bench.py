@@ -75,6 +75,10 @@ def main():
     ap.add_argument('--centre-pairs', action='store_true',
                     help="cfg4: register like the reference (the centre tile's two pairs, on rank 0; stitcher.py:455-485) instead of "
                          'ALL 1 984 adjacent pairs sharded over the ranks (the default: the north star\'s registration)')
+    ap.add_argument('--canvas-order', choices=['spread', 'plane'], default='spread',
+                    help="region workloads: where a (c, z) plane's canvas sits in the canvas allocation.  'spread' (default): "
+                         "z-major, so that the z planes of a channel -- which go through the kernel together -- lie a channel "
+                         "count of planes apart, spread over the whole allocation; 'plane': plane p = c * Z + z at slot p")
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
@@ -264,14 +268,27 @@ def run_region(ctx):
         ffs = [torch.from_numpy(synth.synthetic_flatfield(TILE, TILE, np.float32) * np.float32(1 + 0.03125 * c)).to(dev)
                for c in range(C_eff)]
         flat_list = [ffs[p // Z_eff] for p in range(n_planes)]
-    flat_ptrs = native.pointer_table(flat_list, dev) if flat_list else None
+    # Canvas SLOTS.  The library takes the canvas as base + slot * stride and everything else per slot (tile pointers,
+    # gain pointers), so which (c, z) plane a slot holds is the caller's choice.  The planes that share a gain image go
+    # through the kernel together, and that group writes fastest when its planes lie far apart in device memory
+    # (DESIGN.md 5.1 point 8: stretches of tens of GiB behave like separate resources for this write pattern; the kernel
+    # deals a key's planes to its groups round-robin for the same reason).  'spread': slot s holds channel s % C,
+    # z = s // C -- a channel's planes are C slots apart, over the whole allocation.
+    if args.canvas_order == 'spread':
+        plane_of_slot = [(s % C_eff) * Z_eff + s // C_eff for s in range(n_planes)]
+    else:
+        plane_of_slot = list(range(n_planes))
+    slot_of_plane = {p: s for s, p in enumerate(plane_of_slot)}
+    slot_flats = [flat_list[p] for p in plane_of_slot] if flat_list else None
+    flat_ptrs = native.pointer_table(slot_flats, dev) if slot_flats else None
     # dense rows like the reference's array; every plane starts on a 128-byte line (native.empty_canvas)
     canvas = native.empty_canvas(n_planes, hc, wc, torch.uint16, dev)
+    canvas_of_plane = [canvas[slot_of_plane[p]] for p in range(n_planes)]
     tile_order = torch.tensor(order, dtype=torch.int64)
-    # tile pointer table in write order (plane-major), so rect i <-> pointer i
+    # tile pointer table in write order (slot-major), so rect i <-> pointer i
     esz = TILE * TILE * 2
     base = tiles.data_ptr()
-    ptrs = (base + (torch.arange(n_planes, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
+    ptrs = (base + (torch.tensor(plane_of_slot, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
     ptrs = ptrs.reshape(-1).to(dev)
     reg_plane = tiles[0]   # registration channel = first channel, z level 0 (CLI defaults)
     torch.cuda.synchronize()
@@ -323,7 +340,7 @@ def run_region(ctx):
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        native.fuse_planes(plan, None, canvas, flat_list, tile_ptrs=ptrs, flat_ptrs=flat_ptrs)
+        native.fuse_planes(plan, None, canvas, slot_flats, tile_ptrs=ptrs, flat_ptrs=flat_ptrs)
         if record:
             e1.record()
             fuse_events.append((e0, e1))
@@ -381,7 +398,7 @@ def run_region(ctx):
         'scaling': 'weak' if (world > 1 and args.weak) else 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'config': {'workload': wl['desc'], 'planes_resident_per_gpu': n_planes,
-                   'canvas': [hc, wc], 'tiles_per_plane': g * g,
+                   'canvas': [hc, wc], 'tiles_per_plane': g * g, 'canvas_order': args.canvas_order,
                    'parallelism': f'one region per GPU x{world}, shift-table all-gather' if world > 1 else 'single GPU',
                    'shifts': {'h': list(state['shifts'].h_shift), 'v': list(state['shifts'].v_shift)},
                    'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes; the next '
@@ -399,14 +416,14 @@ def run_region(ctx):
     # accuracy side of the metric (BASELINE.json: shift RMSE <= 0.5 px, fused max-rel-err <= 1e-5)
     out['parity'] = shift_parity(state['shifts'], truth)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas)
+        out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas_of_plane)
         out['cpu_baseline_reference'] = REFERENCE_TIMING
         out['parity'].update(check)
     if world == 1 and args.workload is None and not args.planes and not os.environ.get('SQ_BENCH_NO_REFERENCE_JOB'):
         # The N > 1 runs of this script measure the headline job (cfg4, strong scaling).  For the record, the SAME job on
         # this one GPU (one step after one warm-up, ~3 s): the single-GPU point of that scaling curve, next to the config-3
         # number above, which is this run's `value`.
-        del tiles, canvas, ptrs, flat_list, flat_ptrs, reg_plane
+        del tiles, canvas, canvas_of_plane, ptrs, flat_list, slot_flats, flat_ptrs, reg_plane
         state.clear()
         fuse_events.clear()
         torch.cuda.empty_cache()

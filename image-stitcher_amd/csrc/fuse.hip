@@ -1014,11 +1014,12 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
 // and every plane is its own group.
 __global__ __launch_bounds__(256) void build_groups_kernel(const void *const *flat_ptrs, const uint32_t *cls, uint32_t cls_mask,
                                                           int n_planes, int64_t plane_stride_bytes, int zb, uint32_t *n_groups,
-                                                          PlaneGroup *groups) {
+                                                          PlaneGroup *groups, bool consecutive) {
     // flat_ptrs == NULL (feather without gains): the planes share their geometry only, any of them may go together
     constexpr int CAP = 1024;
     __shared__ uint64_t key[CAP];
     __shared__ int first[CAP], open_group[CAP];
+    __shared__ short members[CAP], dealt[CAP];
     __shared__ PlaneGroup out[CAP];
     const int tid = threadIdx.x;
     if (n_planes > CAP || zb <= 1) {
@@ -1051,18 +1052,38 @@ __global__ __launch_bounds__(256) void build_groups_kernel(const void *const *fl
     }
     __syncthreads();
     if (tid == 0) {
+        // The m planes of one key become ceil(m / zb) groups, and the planes are DEALT to them round-robin in index order
+        // (plane j of the key -> the key's group j mod its group count), not taken five consecutive ones at a time: plane
+        // index = position in the canvas allocation, and the write rate of a group depends on how far apart its planes
+        // lie -- stretches of tens of GiB of device memory behave like separate banks of resources for this access pattern
+        // (row segments at the canvas pitch): planes inside one stretch 0.56 of peak for the bare row fill, planes from two
+        // stretches 0.74 (tools/membw_gains, profiles/r03_exp_*placement*.log, DESIGN.md 5.1 point 8).  Dealing spreads every
+        // group over the whole run of its key's planes; the group sizes come out balanced (4 + 4 + 4 instead of 5 + 5 + 2).
         int ng = 0;
+        for (int p = 0; p < n_planes; ++p) members[p] = dealt[p] = 0;
+        for (int p = 0; p < n_planes; ++p)
+            if (key[p]) ++members[first[p]];           // planes of the key, counted at its first plane (its "lead")
+        for (int p = 0; p < n_planes; ++p) {           // every key its run of group slots, keys in index order
+            if (!key[p]) {
+                open_group[p] = ng++;                  // groups with nobody
+            } else if (first[p] == p) {
+                open_group[p] = ng;
+                ng += (members[p] + zb - 1) / zb;
+            }
+        }
+        for (int g = 0; g < ng; ++g) out[g].n = 0;
         for (int p = 0; p < n_planes; ++p) {
-            const int lead = first[p];
-            int g = key[p] ? open_group[lead] : -1;
-            if (g < 0 || out[g].n >= zb) {
-                g = ng++;
-                out[g].n = 0;
-                for (int z = 0; z < 7; ++z) out[g].plane[z] = p;
-                if (key[p]) open_group[lead] = g;
+            int g = open_group[p];
+            if (key[p]) {
+                const int lead = first[p];
+                const int j = dealt[lead]++;           // consecutive (round 2, for A/B runs): planes j zb .. j zb + zb - 1 together
+                g = open_group[lead] + (consecutive ? j / zb : j % ((members[lead] + zb - 1) / zb));
             }
             out[g].plane[out[g].n++] = p;
         }
+        // unused slots of a group repeat its first plane (the kernels read plane[z] for z < n only; keep the rest valid)
+        for (int g = 0; g < ng; ++g)
+            for (int z = out[g].n; z < 7; ++z) out[g].plane[z] = out[g].plane[0];
         *n_groups = (uint32_t)ng;
         first[0] = ng;
     }
@@ -1770,7 +1791,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
     if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
-    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS | SQ_FUSE_NO_SEAM_OWNERS)) || a->grid_blocks < 0 ||
+    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS | SQ_FUSE_NO_SEAM_OWNERS | SQ_FUSE_CONSECUTIVE_GROUPS)) || a->grid_blocks < 0 ||
         ((a->flags & SQ_FUSE_FORCE_QUEUES) && (a->flags & SQ_FUSE_FORCE_STATIC)))
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: flags %d / grid_blocks %d", a->flags, a->grid_blocks);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
@@ -1852,7 +1873,8 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
             PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
             hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 1u, a->n_planes,
-                               a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
+                               a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                               (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
             P.groups = groups;
             P.n_groups = n_groups;
             if (flat == 2) {
@@ -1895,7 +1917,8 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
         PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
         hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 3u, a->n_planes,
-                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups);
+                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                               (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
         P.groups = groups;
         P.n_groups = n_groups;
         if (flat == 1) {

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get('SQ_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsqui
 SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
-SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS = 1, 2, 4, 8
+SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS, SQ_FUSE_CONSECUTIVE_GROUPS = 1, 2, 4, 8, 16
 SQ_VERSION = 104
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),

@@ -127,7 +127,10 @@ typedef enum sq_fuse_flags {
     SQ_FUSE_FORCE_QUEUES = 1, /* device work queues whatever the launch size (needs scratch_dev) */
     SQ_FUSE_FORCE_STATIC = 2, /* static grid-stride walk whatever the launch size                */
     SQ_FUSE_NO_PLANE_GROUPS = 4, /* uint16 / float32 gains: one plane at a time even where planes share a gain image */
-    SQ_FUSE_NO_SEAM_OWNERS = 8   /* plane groups: both items at a vertical seam write their part of the shared cache line */
+    SQ_FUSE_NO_SEAM_OWNERS = 8,  /* plane groups: both items at a vertical seam write their part of the shared cache line */
+    SQ_FUSE_CONSECUTIVE_GROUPS = 16 /* plane groups: the planes that share a gain image are taken ZB consecutive ones at a time
+                                       (round 2's grouping) instead of being dealt round-robin to the key's groups -- for A/B runs:
+                                       a group writes fastest when its planes lie far apart in device memory */
 } sq_fuse_flags;
 
 int64_t sq_fuse_scratch_bytes(int32_t n_planes);

@@ -442,6 +442,106 @@ int main(int argc, char **argv) {
         if (h) printf("!! %s: %s\n", what, buf);
         return buf;
     };
+    if (argc > 5 && atoi(argv[5]) == 300) {
+        // ADDRESS AXIS: one 64 GiB allocation; "plane" k starts k * STEP bytes into it.  Row fill on the pair (ref, k): which
+        // stretches of the allocation collide with the stretch at `ref`?
+        P.src = src;
+        P.dst = nullptr;
+        const size_t total = (size_t)64 << 30, STEP = (size_t)512 << 20;
+        char *big;
+        CK(hipMalloc(&big, total));
+        const int nk = (int)((total - P.dst_plane) / STEP);
+        printf("one allocation of %zu GiB at %p; plane k at +k * %zu MiB (a plane is %.2f GiB); row fill of the pair (ref, k), fraction of 8 TB/s\n",
+               total >> 30, (void *)big, STEP >> 20, P.dst_plane / 1073741824.0);
+        const double moved1 = moved / Z;
+        const int refs[] = {0, 13, 40};
+        for (int ref : refs) {
+            printf("ref %3d:", ref);
+            for (int k = 0; k < nk; ++k) {
+                if ((size_t)abs(k - ref) * STEP < P.dst_plane) {   // overlapping: skip
+                    printf("  --- ");
+                    continue;
+                }
+                PlanePtrs D{};
+                D.d[0] = big + ref * STEP;
+                D.d[1] = big + k * STEP;
+                const double ms2 = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<2, false>), dim3(items8), dim3(256), 0, 0, P, D); }, 2);
+                printf(" %.3f", 0.5 * 2 * moved1 / ms2 / 1e6 / 8000);
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+        return 0;
+    }
+    if (argc > 5 && atoi(argv[5]) == 200) {
+        // PAIRWISE: N separately allocated canvas planes; the row fill on every PAIR of them (2 planes per thread), on single
+        // planes, and on a few sets of five chosen from the pair matrix
+        P.src = src;
+        P.dst = nullptr;
+        constexpr int N = 14;
+        char *pl[N];
+        size_t sp = 7;
+        for (int i = 0; i < N; ++i) {
+            if (i >= N / 2) {
+                char *spacer;
+                sp = sp * 1103515245u + 12345u;
+                CK(hipMalloc(&spacer, ((sp >> 8) % 997 + 3) << 20));
+            }
+            CK(hipMalloc(&pl[i], P.dst_plane));
+        }
+        const double moved1 = moved / Z;   // pixel bytes read + written of ONE plane
+        static double rate[N][N];
+        for (int i = 0; i < N; ++i) {
+            PlanePtrs D{};
+            D.d[0] = pl[i];
+            const double ms = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<1, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            rate[i][i] = 0.5 * moved1 / ms / 1e6 / 8000;
+            for (int j = i + 1; j < N; ++j) {
+                D.d[1] = pl[j];
+                const double ms2 = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<2, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+                rate[i][j] = rate[j][i] = 0.5 * 2 * moved1 / ms2 / 1e6 / 8000;
+            }
+        }
+        printf("row fill, fraction of 8 TB/s: diagonal = one plane per thread, off-diagonal = the pair (2 planes per thread)\n      ");
+        for (int j = 0; j < N; ++j) printf("  p%02d ", j);
+        printf("\n");
+        for (int i = 0; i < N; ++i) {
+            printf("p%02d %p ", i, (void *)pl[i]);
+            for (int j = 0; j < N; ++j) printf("%.3f ", rate[i][j]);
+            printf("\n");
+        }
+        // greedy sets of five: start from each plane, add the plane whose worst pair rate with the set is best
+        for (int start = 0; start < N; start += 3) {
+            int set[Z] = {start};
+            bool used[N] = {};
+            used[start] = true;
+            for (int k = 1; k < Z; ++k) {
+                int best = -1;
+                double bv = -1;
+                for (int c = 0; c < N; ++c) {
+                    if (used[c]) continue;
+                    double worst = 1e9;
+                    for (int q = 0; q < k; ++q) worst = rate[set[q]][c] < worst ? rate[set[q]][c] : worst;
+                    if (worst > bv) { bv = worst; best = c; }
+                }
+                set[k] = best;
+                used[best] = true;
+            }
+            PlanePtrs D;
+            for (int z = 0; z < Z; ++z) D.d[z] = pl[set[z]];
+            const double msr = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            const double msc = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, true>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            printf("chosen set {%d %d %d %d %d}: row fill %.3f   copy 5 planes/thread %.3f\n", set[0], set[1], set[2], set[3], set[4],
+                   0.5 * moved / msr / 1e6 / 8000, moved / msc / 1e6 / 8000);
+        }
+        {   // and the worst: the first five in allocation order
+            PlanePtrs D;
+            for (int z = 0; z < Z; ++z) D.d[z] = pl[z];
+            const double msr = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+            printf("planes {0 1 2 3 4} as allocated: row fill %.3f\n", 0.5 * moved / msr / 1e6 / 8000);
+        }
+        return 0;
+    }
     if (argc > 5 && atoi(argv[5]) == 100) {
         // PER-PLANE ALLOCATIONS: every canvas plane its own hipMalloc (2 MiB-aligned base, so the row phases inside a
         // 128-byte line are those of the single allocation), a few sets per process, with and without spacer
