@@ -569,13 +569,23 @@ class Stitcher:
     def stitch_region(self, timepoint, region, progress_callback=None, device_output: bool = False):
         """Fuse one (timepoint, region) -> 5-D TCZYX array of the input dtype
         (stitcher.py:639-689).  Returns numpy (host) unless ``device_output``."""
-        planes, _ = self.stitch_planes(timepoint, region, None, progress_callback)
+        # canvas slots z-major ("spread"): the z planes of a channel -- which share a gain image and go through the
+        # fusion kernel together -- then lie num_c planes apart in the canvas allocation instead of side by side; a
+        # group of planes writes fastest when they sit in different stretches of device memory (DESIGN.md 5.1 point 8)
+        planes, _ = self.stitch_planes(timepoint, region, None, progress_callback, slot_order='spread')
         shape = (1, self.num_c, self.num_z, planes.shape[-2], planes.shape[-1])
+        by_cz = planes.unflatten(0, (self.num_z, self.num_c)).transpose(0, 1)   # [C, Z, Hc, Wc] view of the [Z * C] slots
         if device_output:       # a strided view: planes sit on 128-byte lines, rows are dense
-            return planes.unflatten(0, (self.num_c, self.num_z)).unsqueeze(0)
-        return native.planes_to_host(planes).reshape(shape)
+            return by_cz.unsqueeze(0)
+        import torch
+        out = torch.empty(shape, dtype=planes.dtype)
+        for c in range(self.num_c):
+            for z in range(self.num_z):      # one D2H copy per plane (a strided .cpu() would first copy on the device)
+                out[0, c, z].copy_(by_cz[c, z])
+        return out.numpy()
 
-    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None, row_band=None):
+    def stitch_planes(self, timepoint, region, only_planes=None, progress_callback=None, stream_to=None, row_band=None,
+                      slot_order: str = 'plane'):
         """Fuse the (channel, z) planes ``only_planes`` (plane = channel * num_z + z; None = all) of one
         (timepoint, region) -> (device tensor [n, Hc, Wc], sorted plane ids).  Planes are independent,
         which is what lets several GPUs share one region.
@@ -585,7 +595,10 @@ class Stitcher:
         for disk while the next batch is read and fused; the return value is (None, plane ids).
 
         ``row_band`` = (y0, y1): only these canvas rows of the planes (sharding.row_bands -- one plane shared by
-        several GPUs); the canvas is then y1 - y0 rows high, tiles outside the band are not even read."""
+        several GPUs); the canvas is then y1 - y0 rows high, tiles outside the band are not even read.
+
+        ``slot_order``: 'plane' -- the returned tensor's i-th plane is the i-th plane id; 'spread' (all planes only) --
+        plane c * num_z + z sits at slot z * num_c + c, so the planes of a channel are num_c slots apart."""
         import torch
         start_time = time.time()
         region_data = self.get_region_data(int(timepoint), region)
@@ -595,6 +608,12 @@ class Stitcher:
         if plane_ids and (plane_ids[0] < 0 or plane_ids[-1] >= self.num_c * self.num_z):
             raise ValueError(f"plane ids must lie in [0, {self.num_c * self.num_z})")
         slot_of = {p: i for i, p in enumerate(plane_ids)}
+        if slot_order == 'spread':
+            if only_planes is not None or stream_to is not None:
+                raise ValueError("slot_order='spread' lays out ALL planes of a region in one canvas")
+            slot_of = {p: (p % self.num_z) * self.num_c + p // self.num_z for p in plane_ids}
+        elif slot_order != 'plane':
+            raise ValueError(f"slot_order must be 'plane' or 'spread', got {slot_order!r}")
         print(f"region {region} timepoint {timepoint} output array dimensions: "
               f"{(1, self.num_c, self.num_z, height, width)}" + ("" if only_planes is None else f", planes {plane_ids}"))
         # dense rows like the reference's array, every plane on a 128-byte line (native.empty_canvas)
@@ -723,8 +742,11 @@ class Stitcher:
                     if writer is not None:
                         native.fuse_planes(plan, tiles, writer.acquire(m), flats)
                         writer.submit([(0, p // self.num_z, p % self.num_z) for p in chunk])
-                    elif all(slots[i] + 1 == slots[i + 1] for i in range(m - 1)):
-                        native.fuse_planes(plan, tiles, flat_canvas[slots[0]:slots[0] + m], flats)
+                    elif m == 1 or (slots[1] > slots[0] and all(slots[i + 1] - slots[i] == slots[1] - slots[0] for i in range(m - 1))):
+                        # the chunk's canvas slots are evenly spaced (side by side, or num_c apart with slot_order
+                        # 'spread'): ONE launch on the strided view
+                        step = slots[1] - slots[0] if m > 1 else 1
+                        native.fuse_planes(plan, tiles, flat_canvas[slots[0]:slots[0] + (m - 1) * step + 1:step], flats)
                     else:
                         for pi, sl in enumerate(slots):
                             native.fuse_planes(plan, tiles[pi:pi + 1], flat_canvas[sl:sl + 1],

@@ -468,12 +468,20 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
         native.fuse_planes(plan, d_tiles, aligned, None, flags=flags)
         native.fuse_planes(plan, d_tiles, dense, None, flags=flags)
     torch.cuda.synchronize()
+    # round 3: the planes of a key are DEALT to its groups round-robin (the default above); round 2's grouping -- five
+    # consecutive planes of a key at a time -- must give the same voxels (SQ_FUSE_CONSECUTIVE_GROUPS, kept for A/B runs)
+    consecutive = native.empty_canvas(planes, ch, cw, torch.uint16, dev)
+    consecutive.view(torch.int16).fill_(-1)
+    native.fuse_planes(plan, d_tiles, consecutive, flats if any(f is not None for f in flats) else None,
+                       flags=flags | native.SQ_FUSE_CONSECUTIVE_GROUPS)
+    torch.cuda.synchronize()
     for p in range(planes):
         g = None if which[p] < 0 else gains[which[p]]
         want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, g) if mode == native.SQ_FUSE_OVERWRITE else \
             O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, g, out_dtype=np.uint16)
         np.testing.assert_array_equal(aligned[p].cpu().numpy(), want, err_msg=f'plane {p} (gain image {which[p]}) of {planes}')
         np.testing.assert_array_equal(dense[p].cpu().numpy(), want, err_msg=f'dense plane {p}')
+        np.testing.assert_array_equal(consecutive[p].cpu().numpy(), want, err_msg=f'plane {p}, groups of consecutive planes')
 
 
 @pytest.mark.gpu
