@@ -334,18 +334,6 @@ __device__ __forceinline__ void small_dft(cplx (&a)[R], const cplx *__restrict__
         a[4] = csub(m1, n1);
         a[2] = cadd(m2, n2);
         a[3] = csub(m2, n2);
-    } else {   // 7, 11, 13: the plain sum with table twiddles W_R^((q j) mod R)
-        const int step = N / R;
-        cplx y[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            cplx acc = a[0];
-#pragma unroll
-            for (int q = 1; q < R; ++q) acc = cadd(acc, cmul(a[q], twiddle<INV>(tw, ((q * j) % R) * step)));
-            y[j] = acc;
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) a[j] = y[j];
     }
 }
 template <int R, bool INV, bool DIF>
@@ -357,13 +345,27 @@ __device__ __forceinline__ void butterfly(cplx *x, int stride, int k, int tws, i
 #pragma unroll
         for (int q = 1; q < R; ++q) a[q] = cmul(twiddle<INV>(tw, q * k * tws), a[q]);
     }
-    small_dft<R, INV>(a, tw, N);
-    if (DIF && k) {
+    if (R <= 5) {
+        small_dft<R, INV>(a, tw, N);
+        if (DIF && k) {
 #pragma unroll
-        for (int j = 1; j < R; ++j) a[j] = cmul(twiddle<INV>(tw, j * k * tws), a[j]);
+            for (int j = 1; j < R; ++j) a[j] = cmul(twiddle<INV>(tw, j * k * tws), a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j * stride] = a[j];
+    } else {
+        // 7, 11, 13: the plain sum with table twiddles W_R^((q j) mod R); every input is in registers, so each output
+        // goes straight back to its place (an output array would double the registers: 13 complex128 = 52 VGPRs)
+        const int step = N / R;
+#pragma unroll 1
+        for (int j = 0; j < R; ++j) {      // (not unrolled: R outputs' worth of hoisted twiddles would fill the register file)
+            cplx acc = a[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) acc = cadd(acc, cmul(a[q], twiddle<INV>(tw, ((q * j) % R) * step)));
+            if (DIF && k && j) acc = cmul(twiddle<INV>(tw, j * k * tws), acc);
+            x[j * stride] = acc;
+        }
     }
-#pragma unroll
-    for (int j = 0; j < R; ++j) x[j * stride] = a[j];
 }
 // `nlines` contiguous lines of N points each; the caller has synchronised; returns synchronised
 template <bool INV, bool DIF>
@@ -395,10 +397,14 @@ __device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__res
 }
 // one transform of length pl.len: natural -> plan order (BWD = false) or plan order -> natural (BWD = true); for a
 // power of two both orders are the natural one
-template <bool INV, bool BWD>
+// GEN = false: the instantiation for power-of-two transforms only (the host picks it when the axis' plan has no
+// mixed-radix stage) -- the radix-13 butterfly alone holds 13 complex128 in registers, and a kernel that merely CONTAINS
+// it is allocated for it: the power-of-two kernels would drop from 8+ to 2 waves per SIMD (measured: 1 984 pairs of
+// 1024 x 256 in 57 instead of 29 ms)
+template <bool INV, bool BWD, bool GEN>
 __device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
-    if (!pl.nf) lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
-    else lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
+    if (GEN && pl.nf) lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
+    else lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
 }
 
 // Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
@@ -415,11 +421,11 @@ __device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cpl
 //   BWD = false ("first" transform): natural-order input  -> frequency k at position pos_of(X, k);
 //   BWD = true  ("second"):          input with frequency k at pos_of(X, k) -> natural-order output.
 // pos_of is the identity except for a mixed-radix direct transform.
-template <bool INV, bool BWD>
+template <bool INV, bool BWD, bool GEN>
 __device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt) {
     const int n = X.n;
     if (!X.m) {
-        lines_fft_plan<INV, BWD>(base, nlines, X.tw, X.pl, tid, nt);
+        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt);
         return;
     }
     const int M = X.m;
@@ -434,10 +440,10 @@ __device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt
         base[e] = v;
     }
     __syncthreads();
-    lines_fft_plan<false, false>(base, nlines, X.twm, X.pl, tid, nt);
+    lines_fft_plan<false, false, GEN>(base, nlines, X.twm, X.pl, tid, nt);
     for (int e = tid; e < nlines * M; e += nt) base[e] = cmul(base[e], X.spec[e % M]);
     __syncthreads();
-    lines_fft_plan<true, true>(base, nlines, X.twm, X.pl, tid, nt);
+    lines_fft_plan<true, true, GEN>(base, nlines, X.twm, X.pl, tid, nt);
     const double inv_m = 1.0 / (double)M;
     for (int e = tid; e < nlines * M; e += nt) {
         const int j = e % M;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
         x[j] = v;
     }
     __syncthreads();
-    lines_fft_plan<false, false>(x, 1, twm, axis ? L.ax1 : L.ax0, tid, nt);
+    lines_fft_plan<false, false, true>(x, 1, twm, axis ? L.ax1 : L.ax0, tid, nt);
     for (int j = tid; j < M; j += nt) spec[j] = x[j];
 }
 
@@ -628,7 +634,7 @@ __device__ __forceinline__ double normalised(const T *tile, int64_t idx, double 
 // One block = P.rl consecutive rows of one pair (as many as fit 64 KB of LDS, at most 8), sent through
 // the line FFT together: one barrier per pass for the batch, and eight times fewer, fuller blocks
 // than one row per block.
-template <typename T>
+template <typename T, bool GEN>
 __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
         x[(int64_t)l * ld + j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     }
     __syncthreads();
-    lines_fft<false, false>(x, X, nrow, tid, nt);
+    lines_fft<false, false, GEN>(x, X, nrow, tid, nt);
     for (int e = tid; e < nrow * n1h; e += nt) {
         const int l = e / n1h, k = e - l * n1h;
         const cplx *xl = x + (int64_t)l * ld;
@@ -683,6 +689,7 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
 #ifndef SQ_COL_THREADS
 #define SQ_COL_THREADS 512
 #endif
+template <bool GEN>
 __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
@@ -703,10 +710,10 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     __syncthreads();
     const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
-        lines_fft<false, false>(f, X, 2 * tc, tid, nt);
+        lines_fft<false, false, GEN>(f, X, 2 * tc, tid, nt);
     } else {
-        lines_fft<false, false>(f, X, ncol, tid, nt);
-        lines_fft<false, false>(g, X, ncol, tid, nt);
+        lines_fft<false, false, GEN>(f, X, ncol, tid, nt);
+        lines_fft<false, false, GEN>(g, X, ncol, tid, nt);
     }
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + pos_of(X, r)];
     }
     __syncthreads();
-    lines_fft<true, true>(f, X, ncol, tid, nt);
+    lines_fft<true, true, GEN>(f, X, ncol, tid, nt);
     for (int i = tid; i < n0 * ncol; i += nt) {
         const int r = i / ncol, c = i - r * ncol;
         A[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
@@ -763,6 +770,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
 // length that needs Bluestein, and for direct lengths too long for two of them to share the LDS (n0 > 4608).  The
 // column spectra F and G go back to the workspace between the three transforms instead of staying in LDS -- every
 // thread re-reads exactly the elements it wrote.
+template <bool GEN>
 __global__ __launch_bounds__(SQ_COL_THREADS) void columns_single_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
@@ -776,12 +784,12 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_single_kernel(RegParam
     const Axis X = axis_of(P, 0);
     for (int r = tid; r < n0; r += nt) x[r] = A[(int64_t)r * n1h];
     __syncthreads();
-    lines_fft<false, false>(x, X, 1, tid, nt);
+    lines_fft<false, false, GEN>(x, X, 1, tid, nt);
     for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[pos_of(X, r)];   // F, natural order; re-read below by this very thread
     __syncthreads();
     for (int r = tid; r < n0; r += nt) x[r] = B[(int64_t)r * n1h];
     __syncthreads();
-    lines_fft<false, false>(x, X, 1, tid, nt);
+    lines_fft<false, false, GEN>(x, X, 1, tid, nt);
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double sf = 0.0, sg = 0.0;
     for (int r = tid; r < n0; r += nt) {
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_single_kernel(RegParam
         amps[0] = a;
         amps[1] = b;
     }
-    lines_fft<true, true>(x, X, 1, tid, nt);
+    lines_fft<true, true, GEN>(x, X, 1, tid, nt);
     for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[r];
 }
 
@@ -874,6 +882,7 @@ __device__ __forceinline__ Best wave_best(Best b) {
     return b;
 }
 
+template <bool GEN>
 __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
         x[(int64_t)l * ld + pos_of(X, k)] = {a.re - b.im, a.im + b.re};   // a + i b, where the second transform wants frequency k
     }
     __syncthreads();
-    lines_fft<true, true>(x, X, nline, tid, nt);
+    lines_fft<true, true, GEN>(x, X, nline, tid, nt);
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int l = wave; l < nline; l += nw) {
         const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);
@@ -1292,24 +1301,36 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.rl_inv = rli;
     const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
     const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
+    // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
+    const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
+#define SQ_LAUNCH(KERNEL, GRID, THREADS, LDS)                                        \
+    do {                                                                             \
+        if ((rc = allow_lds(KERNEL, LDS)) != SQ_OK) return rc;                       \
+        hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, s, P);                  \
+    } while (0)
+    const dim3 grid_fwd((L.n0 + rlf - 1) / rlf, a->n_pairs);
     if (a->tile_dtype == SQ_U16) {
-        if ((rc = allow_lds(rows_forward_kernel<uint16_t>, lds_fwd)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(rows_forward_kernel<uint16_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
+        if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true>), grid_fwd, ntf, lds_fwd);
+        else SQ_LAUNCH((rows_forward_kernel<uint16_t, false>), grid_fwd, ntf, lds_fwd);
     } else {
-        if ((rc = allow_lds(rows_forward_kernel<uint8_t>, lds_fwd)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(rows_forward_kernel<uint8_t>, dim3((L.n0 + rlf - 1) / rlf, a->n_pairs), dim3(ntf), lds_fwd, s, P);
+        if (gen1) SQ_LAUNCH((rows_forward_kernel<uint8_t, true>), grid_fwd, ntf, lds_fwd);
+        else SQ_LAUNCH((rows_forward_kernel<uint8_t, false>), grid_fwd, ntf, lds_fwd);
     }
     if (tc < 1) {
         const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
-        if ((rc = allow_lds(columns_single_kernel, lds_col)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(columns_single_kernel, dim3(L.n1h, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+        const dim3 grid_col(L.n1h, a->n_pairs);
+        if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
+        else SQ_LAUNCH(columns_single_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
     } else {
         const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
-        if ((rc = allow_lds(columns_kernel, lds_col)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(columns_kernel, dim3((L.n1h + tc - 1) / tc, a->n_pairs), dim3(SQ_COL_THREADS), lds_col, s, P);
+        const dim3 grid_col((L.n1h + tc - 1) / tc, a->n_pairs);
+        if (gen0) SQ_LAUNCH(columns_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
+        else SQ_LAUNCH(columns_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
     }
-    if ((rc = allow_lds(rows_inverse_kernel, lds_inv)) != SQ_OK) return rc;
-    hipLaunchKernelGGL(rows_inverse_kernel, dim3(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs), dim3(nti), lds_inv, s, P);
+    const dim3 grid_inv(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs);
+    if (gen1) SQ_LAUNCH(rows_inverse_kernel<true>, grid_inv, nti, lds_inv);
+    else SQ_LAUNCH(rows_inverse_kernel<false>, grid_inv, nti, lds_inv);
+#undef SQ_LAUNCH
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
         if ((int64_t)a->n_pairs * ((L.n0 + 127) / 128) >= 256)

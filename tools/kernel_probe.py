@@ -19,6 +19,7 @@ def timed(fn, reps=3):
     return best
 
 
+only_reg = len(sys.argv) > 1 and sys.argv[1] == 'registration'
 # ---- chunk encoder ------------------------------------------------------------------------------------------------
 H, W, P = 8192, 8192, 8
 rng = np.random.default_rng(0)
@@ -28,7 +29,7 @@ kinds = {
     'hash noise (the bench tiles: incompressible)': lambda: synth.scene_patch(3, 0, 0, H, W).astype(np.uint16),
     'zeros': lambda: np.zeros((H, W), np.uint16),
 }
-for name, make in kinds.items():
+for name, make in ({} if only_reg else kinds).items():
     plane = torch.from_numpy(make()).to(dev)
     planes = plane[None].repeat(P, 1, 1).contiguous()
     buf = native.BloscBuffers(P, H, W, np.uint16, 512, 512, dev)
@@ -41,7 +42,7 @@ for name, make in kinds.items():
 # ---- BaSiC ---------------------------------------------------------------------------------------------------------
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from test_basic_oracle_cpu import planted_stack
-for n, h, w in ((48, 2048, 2048), (33, 512, 512)):
+for n, h, w in (() if only_reg else ((48, 2048, 2048), (33, 512, 512))):
     stack, gain = planted_stack(n, h, w, seed=1, objects=max(6, 30 * h * w // (256 * 320)))
     t = torch.from_numpy(stack).to(dev)
     native.basic_fit(t)
@@ -52,8 +53,10 @@ for n, h, w in ((48, 2048, 2048), (33, 512, 512)):
     print(f'basic_fit {n} x {h}x{w}: {dt * 1e3:.1f} ms, {info}, planted-gain error mean {err.mean():.4f}', flush=True)
 
 # ---- registration batches -----------------------------------------------------------------------------------------
-for (th, tw, ov, label) in ((2048, 2048, 244, 'power-of-two crops 1024 x 256'), (4168, 6244, 300, 'Bluestein crops (6244 x 4168 sensor)')):
-    g = 6
+for (th, tw, ov, label) in ((2048, 2048, 244, 'power-of-two crops 1024 x 256'), (4168, 6244, 300, 'Bluestein crops (6244 x 4168 sensor)'),
+                            (3000, 3000, 288, 'mixed-radix crops (3000 x 3000 sensor: 1500 = 2^2 3 5^3)'),
+                            (6380, 9568, 300, 'long Bluestein crops (9568 x 6380 sensor: 4784, 3190)')):
+    g = 6 if th * tw <= 30e6 else 4
     tiles = torch.from_numpy(rng.integers(0, 65535, (g * g, th, tw)).astype(np.uint16)).to(dev)
     mm = native.tile_minmax(tiles)
     (hp, (h0, h1)), (vp, (v0, v1)) = registration.all_pairs(g, g, th, tw, ov + 12, ov + 12)
