@@ -16,12 +16,15 @@ N > 1 (default workload ``cfg4`` = BASELINE.json configs[3], the configuration t
 32x32 grid of 2048x2048 tiles, 4 channels x 50 z = 200 (c, z) planes = 1.6 TiB of tiles, ``-r -ff``.  STRONG
 scaling: every rank takes ONE contiguous run of the 200 planes (sharding.contiguous_blocks: a channel's z planes
 stay together and go through the kernel in full groups), no image data is
-exchanged; rank 0 registers the centre pairs and the shift row is all-gathered over RCCL once per step.  A rank
-walks its planes in HBM-resident batches (tiles + canvases of a batch fill the card); a batch's tiles are
-synthesised on the device BEFORE that batch's timed segment starts (inputs resident when timing starts, as the
-contract says; the generator is not part of the hot path).  One step = the whole 200-plane job; the timed
-seconds of a rank are registration + all-gather + plan + the fusion launches of all its batches, and the job
-time is the MAX over ranks.  ``--workload cfg4`` runs the same job on one GPU.
+exchanged.  Registration is the north star's: ALL 1 984 adjacent pairs of the registration plane, dealt over the ranks in
+contiguous runs of the tile-row-ordered pair list (a rank holds only the tiles its pairs touch), the [n_pairs, 3]
+float64 table {dy, dx, err} all-gathered over RCCL once per step, per-axis median on every rank (--centre-pairs: the
+reference's two centre pairs on rank 0 and an 8-int32 row instead).  A rank walks its planes in HBM-resident batches
+(tiles + canvases of a batch fill the card); a batch's tiles are synthesised on the device BEFORE that batch's launch,
+outside its event pair (inputs resident when timing starts, as the contract says; the generator is not part of the
+hot path).  One step = the whole 200-plane job; the timed seconds of a rank are registration + all-gather + plan
+(built and uploaded inside the first timed job, re-used while the shifts stay) + the fusion launches of all its
+batches, and the job time is the MAX over ranks.  ``--workload cfg4`` runs the same job on one GPU.
 
 Printed JSON (rank 0, one line): whole-job Mvoxel/s, plus
   roofline     fusion kernel, algorithmic bytes / HIP-event launch time vs 8 TB/s HBM peak (rank 0's launches)
