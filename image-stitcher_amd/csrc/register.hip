@@ -82,19 +82,47 @@ inline bool factor_plan(int len, AxisPlan &pl) {
     pl.nf = nf;
     return true;
 }
-inline bool is_smooth7(int v) {
-    for (int p : {2, 3, 5, 7})
-        while (v % p == 0) v /= p;
-    return v == 1;
+// rough cost of one pass of a stage, per point: the LDS round trip (1) + the butterfly's arithmetic (the 7 / 11 / 13 ones
+// are plain O(r^2) sums)
+inline double stage_cost(int r) {
+    switch (r) {
+        case 2: return 2.0;
+        case 4: return 2.2;
+        case 3: return 2.3;
+        case 5: return 3.0;
+        case 7: return 9.0;
+        case 11: return 15.0;
+        default: return 18.0;
+    }
 }
-// Bluestein length of an n-point line: 0 when n itself is smooth (no chirp needed), else the smallest 2-3-5-7-smooth
-// M >= 2n - 1; -1 when that does not fit a line
+inline double plan_cost(const AxisPlan &pl) {
+    if (!pl.nf) {   // power of two: the fused radix-2 kernel, two stages per LDS pass
+        int lg = 0;
+        while ((1 << lg) < pl.len) ++lg;
+        return pl.len * (1.1 * lg);
+    }
+    double c = 0.0;
+    for (int s = 0; s < pl.nf; ++s) c += stage_cost(pl.radix[s]);
+    return pl.len * c;
+}
+// Bluestein length of an n-point line: 0 when n itself is smooth (no chirp needed), else the CHEAPEST smooth M in
+// [2n - 1, 2n - 1 + n/4] (not simply the smallest: 2084 -> 4320 = 2^5 3^3 5 rather than 4200 = 2^3 3 5^2 7, whose radix-7
+// stage costs more than the 3 % of extra points; 3122 -> 6400 = 2^8 5^2 rather than 6250 = 2 5^5); -1 when none fits a line
 inline int bluestein_m(int n) {
     AxisPlan pl;
     if (factor_plan(n, pl)) return 0;
-    for (int m = 2 * n - 1; m <= MAX_LINE; ++m)
-        if (is_smooth7(m)) return m;
-    return -1;
+    int best = -1;
+    double best_cost = 0.0;
+    const int hi = std::min(MAX_LINE, 2 * n - 1 + n / 4);
+    for (int m = 2 * n - 1; m <= hi; ++m) {
+        if (!factor_plan(m, pl)) continue;
+        const double c = plan_cost(pl);
+        if (best < 0 || c < best_cost) {
+            best = m;
+            best_cost = c;
+        }
+    }
+    return best;
 }
 inline bool line_supported(int n) { return n >= 2 && n <= MAX_LINE && bluestein_m(n) >= 0; }
 inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
@@ -174,6 +202,7 @@ struct RegParams {
     char *ws;
     Layout L;
     int32_t n_pairs, normalization, tc, rl_fwd, rl_inv;   // tc: columns per block (K2); rl_*: lines per block (K1, K3)
+    int32_t twl0, twl1;   // the kernels of axis 0 / 1 have LDS for the twiddle half table behind their lines
     int32_t n_tiles, tile_h, tile_w;
 };
 
@@ -188,6 +217,7 @@ struct Axis {
     const cplx *w;         // chirp w[j] = exp(-i pi j^2 / n), j < n  (Bluestein)
     const cplx *spec;      // FFT_m of conj(w) laid out circularly, in the order the forward m-point transform leaves it
     const int *perm;       // mixed-radix direct transform: frequency k sits at position perm[k]; else NULL (identity)
+    bool tw_lds;           // tw points at a copy of the table's first half in LDS (stage_twiddles)
 };
 
 __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
@@ -202,7 +232,17 @@ __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
     X.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
     X.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
     X.perm = (!X.m && X.pl.nf) ? reinterpret_cast<const int *>(P.ws + (axis ? L.perm1 : L.perm0)) : nullptr;
+    X.tw_lds = false;
     return X;
+}
+// A directly transformed power-of-two axis whose kernel has n / 2 spare complex128 of LDS behind its lines (the host
+// says so in P.twl): the block copies the half table the radix-2 passes index (k < n / 2) into LDS once.  The caller
+// synchronises before the transform (every kernel does, after loading its lines).
+__device__ __forceinline__ void stage_twiddles(Axis &X, cplx *lds_tw, bool enabled, int tid, int nt) {
+    if (!enabled || X.m || X.pl.nf) return;
+    for (int i = tid; i < X.n / 2; i += nt) lds_tw[i] = X.tw[i];
+    X.tw = lds_tw;
+    X.tw_lds = true;
 }
 // where frequency k of a transformed line sits (and where it has to be put before the second transform)
 __device__ __forceinline__ int pos_of(const Axis &X, int k) { return X.perm ? X.perm[k] : k; }
@@ -234,9 +274,21 @@ __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
     if (INV) w.im = -w.im;
     return w;
 }
-
+// the same from a table the block has copied into LDS (ds_read_b128 instead of a global load per butterfly operand)
+typedef __attribute__((address_space(3))) const cplx lds_const_cplx;
 template <bool INV>
-__device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
+__device__ __forceinline__ cplx twiddle_lds(const cplx *tw, int idx) {
+    lds_const_cplx *p = reinterpret_cast<lds_const_cplx *>(reinterpret_cast<uintptr_t>(tw) & 0xFFFFFFFFu) + idx;
+    const double re = p->re, im = p->im;
+    return {re, INV ? -im : im};
+}
+template <bool INV, bool TWLDS>
+__device__ __forceinline__ cplx twiddle2(const cplx *tw, int idx) {
+    return TWLDS ? twiddle_lds<INV>(tw, idx) : twiddle<INV>(tw, idx);
+}
+
+template <bool INV, bool TWLDS = false>
+__device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *tw, int tid, int nt) {
     const int logn = 31 - __clz(n);
     for (int e = tid; e < nlines * n; e += nt) {
         const int i = e & (n - 1);
@@ -253,7 +305,7 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
     if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
         for (int e = tid; e < nlines * (n >> 1); e += nt) {
             cplx *x = base + 2 * (int64_t)e;
-            const cplx t = cmul(twiddle<INV>(tw, 0), x[1]);
+            const cplx t = cmul(twiddle2<INV, TWLDS>(tw, 0), x[1]);
             const cplx u = x[0];
             x[0] = cadd(u, t);
             x[1] = csub(u, t);
@@ -269,8 +321,8 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
             const int l = e / quads, q = e - l * quads;
             const int k = q & (half - 1);
             cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
-            const cplx w1 = twiddle<INV>(tw, k * ts1);
-            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
+            const cplx w1 = twiddle2<INV, TWLDS>(tw, k * ts1);
+            const cplx w2 = twiddle2<INV, TWLDS>(tw, k * ts2), w3 = twiddle2<INV, TWLDS>(tw, (k + half) * ts2);
             const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
             // stage s: (x0, x1) and (x2, x3), both with w1
             const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
@@ -302,17 +354,17 @@ __device__ __forceinline__ cplx rot90(cplx a) {   // a * (-i) forward, a * (+i) 
 }
 template <int R, bool INV>
 __device__ __forceinline__ void small_dft(cplx (&a)[R], const cplx *__restrict__ tw, int N) {
-    if (R == 2) {
+    if constexpr (R == 2) {
         const cplx u = a[0], v = a[1];
         a[0] = cadd(u, v);
         a[1] = csub(u, v);
-    } else if (R == 4) {
+    } else if constexpr (R == 4) {
         const cplx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = rot90<INV>(csub(a[1], a[3]));
         a[0] = cadd(t0, t2);
         a[2] = csub(t0, t2);
         a[1] = cadd(t1, t3);
         a[3] = csub(t1, t3);
-    } else if (R == 3) {
+    } else if constexpr (R == 3) {
         const double S3 = 0.86602540378443864676;
         const cplx t1 = cadd(a[1], a[2]);
         const cplx t2 = {a[0].re - 0.5 * t1.re, a[0].im - 0.5 * t1.im};
@@ -321,7 +373,7 @@ __device__ __forceinline__ void small_dft(cplx (&a)[R], const cplx *__restrict__
         a[0] = cadd(a[0], t1);
         a[1] = cadd(t2, t3);
         a[2] = csub(t2, t3);
-    } else if (R == 5) {
+    } else if constexpr (R == 5) {
         const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;
         const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
         const cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
@@ -345,7 +397,7 @@ __device__ __forceinline__ void butterfly(cplx *x, int stride, int k, int tws, i
 #pragma unroll
         for (int q = 1; q < R; ++q) a[q] = cmul(twiddle<INV>(tw, q * k * tws), a[q]);
     }
-    if (R <= 5) {
+    if constexpr (R <= 5) {
         small_dft<R, INV>(a, tw, N);
         if (DIF && k) {
 #pragma unroll
@@ -402,9 +454,11 @@ __device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__res
 // it is allocated for it: the power-of-two kernels would drop from 8+ to 2 waves per SIMD (measured: 1 984 pairs of
 // 1024 x 256 in 57 instead of 29 ms)
 template <bool INV, bool BWD, bool GEN>
-__device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
+__device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *tw, const AxisPlan &pl, int tid, int nt,
+                                               bool tw_in_lds = false) {
     if (GEN && pl.nf) lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
-    else lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
+    else if (!GEN && tw_in_lds) lines_fft_pow2<INV, true>(base, pl.len, nlines, tw, tid, nt);
+    else lines_fft_pow2<INV, false>(base, pl.len, nlines, tw, tid, nt);
 }
 
 // Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
@@ -425,7 +479,7 @@ template <bool INV, bool BWD, bool GEN>
 __device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt) {
     const int n = X.n;
     if (!X.m) {
-        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt);
+        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt, X.tw_lds);
         return;
     }
     const int M = X.m;
@@ -639,9 +693,10 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
-    const Axis X = axis_of(P, 1);
+    Axis X = axis_of(P, 1);
     const int ld = X.ld;                           // line pitch: the Bluestein length when n1 needs one
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
+    if (!GEN) stage_twiddles(X, x + (int64_t)rl * ld, P.twl1 != 0, threadIdx.x, blockDim.x);
     const int pair = blockIdx.y, r0 = blockIdx.x * rl;
     const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
@@ -707,8 +762,9 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         f[(int64_t)c * n0 + r] = A[(int64_t)r * n1h + c0 + c];
         g[(int64_t)c * n0 + r] = B[(int64_t)r * n1h + c0 + c];
     }
+    Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
+    if (!GEN) stage_twiddles(X, g + (int64_t)tc * n0, P.twl0 != 0, tid, nt);
     __syncthreads();
-    const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
         lines_fft<false, false, GEN>(f, X, 2 * tc, tid, nt);
     } else {
@@ -888,9 +944,10 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
     const int nrp = (n0 + 1) / 2;
-    const Axis X = axis_of(P, 1);
+    Axis X = axis_of(P, 1);
     const int ld = X.ld;
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
+    if (!GEN) stage_twiddles(X, x + (int64_t)rl * ld, P.twl1 != 0, threadIdx.x, blockDim.x);
     const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
     const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1300,7 +1357,15 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.rl_fwd = rlf;
     P.rl_inv = rli;
     const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
-    const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
+    size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
+    // a directly transformed power-of-two axis: the half twiddle table rides in LDS behind the lines where it fits
+    const size_t LDS_MAX = 160 * 1024 - 1024;
+    const size_t tw1_bytes = (size_t)L.n1 / 2 * 16, tw0_bytes = (size_t)L.n0 / 2 * 16;
+    P.twl1 = (!L.m1 && !L.ax1.nf && std::max(lds_fwd, lds_inv) + tw1_bytes <= LDS_MAX) ? 1 : 0;
+    if (P.twl1) {
+        lds_fwd += tw1_bytes;
+        lds_inv += tw1_bytes;
+    }
     // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
     const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
 #define SQ_LAUNCH(KERNEL, GRID, THREADS, LDS)                                        \
@@ -1322,7 +1387,9 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
         else SQ_LAUNCH(columns_single_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
     } else {
-        const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
+        size_t lds_col = (size_t)2 * tc * L.n0 * 16;
+        P.twl0 = (!L.ax0.nf && lds_col + tw0_bytes <= LDS_MAX) ? 1 : 0;
+        if (P.twl0) lds_col += tw0_bytes;
         const dim3 grid_col((L.n1h + tc - 1) / tc, a->n_pairs);
         if (gen0) SQ_LAUNCH(columns_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
         else SQ_LAUNCH(columns_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
