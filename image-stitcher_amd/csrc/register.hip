@@ -202,7 +202,6 @@ struct RegParams {
     char *ws;
     Layout L;
     int32_t n_pairs, normalization, tc, rl_fwd, rl_inv;   // tc: columns per block (K2); rl_*: lines per block (K1, K3)
-    int32_t twl0, twl1;   // the kernels of axis 0 / 1 have LDS for the twiddle half table behind their lines
     int32_t n_tiles, tile_h, tile_w;
 };
 
@@ -217,7 +216,6 @@ struct Axis {
     const cplx *w;         // chirp w[j] = exp(-i pi j^2 / n), j < n  (Bluestein)
     const cplx *spec;      // FFT_m of conj(w) laid out circularly, in the order the forward m-point transform leaves it
     const int *perm;       // mixed-radix direct transform: frequency k sits at position perm[k]; else NULL (identity)
-    bool tw_lds;           // tw points at a copy of the table's first half in LDS (stage_twiddles)
 };
 
 __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
@@ -232,17 +230,7 @@ __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
     X.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
     X.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
     X.perm = (!X.m && X.pl.nf) ? reinterpret_cast<const int *>(P.ws + (axis ? L.perm1 : L.perm0)) : nullptr;
-    X.tw_lds = false;
     return X;
-}
-// A directly transformed power-of-two axis whose kernel has n / 2 spare complex128 of LDS behind its lines (the host
-// says so in P.twl): the block copies the half table the radix-2 passes index (k < n / 2) into LDS once.  The caller
-// synchronises before the transform (every kernel does, after loading its lines).
-__device__ __forceinline__ void stage_twiddles(Axis &X, cplx *lds_tw, bool enabled, int tid, int nt) {
-    if (!enabled || X.m || X.pl.nf) return;
-    for (int i = tid; i < X.n / 2; i += nt) lds_tw[i] = X.tw[i];
-    X.tw = lds_tw;
-    X.tw_lds = true;
 }
 // where frequency k of a transformed line sits (and where it has to be put before the second transform)
 __device__ __forceinline__ int pos_of(const Axis &X, int k) { return X.perm ? X.perm[k] : k; }
@@ -274,21 +262,11 @@ __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
     if (INV) w.im = -w.im;
     return w;
 }
-// the same from a table the block has copied into LDS (ds_read_b128 instead of a global load per butterfly operand)
-typedef __attribute__((address_space(3))) const cplx lds_const_cplx;
+// (The half twiddle table copied into LDS per block -- ds_read instead of L1-cached global loads -- was built and
+// measured in round 3: 1 984 pairs of 1024 x 256 in 33.3 instead of 30.0 ms, 42-44 k instead of 46-50 k pairs/s in
+// 30-pair batches.  The table is L1-resident; the LDS copy only costs occupancy and LDS bandwidth.  Not kept.)
 template <bool INV>
-__device__ __forceinline__ cplx twiddle_lds(const cplx *tw, int idx) {
-    lds_const_cplx *p = reinterpret_cast<lds_const_cplx *>(reinterpret_cast<uintptr_t>(tw) & 0xFFFFFFFFu) + idx;
-    const double re = p->re, im = p->im;
-    return {re, INV ? -im : im};
-}
-template <bool INV, bool TWLDS>
-__device__ __forceinline__ cplx twiddle2(const cplx *tw, int idx) {
-    return TWLDS ? twiddle_lds<INV>(tw, idx) : twiddle<INV>(tw, idx);
-}
-
-template <bool INV, bool TWLDS = false>
-__device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *tw, int tid, int nt) {
+__device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
     const int logn = 31 - __clz(n);
     for (int e = tid; e < nlines * n; e += nt) {
         const int i = e & (n - 1);
@@ -305,7 +283,7 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *tw, in
     if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
         for (int e = tid; e < nlines * (n >> 1); e += nt) {
             cplx *x = base + 2 * (int64_t)e;
-            const cplx t = cmul(twiddle2<INV, TWLDS>(tw, 0), x[1]);
+            const cplx t = cmul(twiddle<INV>(tw, 0), x[1]);
             const cplx u = x[0];
             x[0] = cadd(u, t);
             x[1] = csub(u, t);
@@ -321,8 +299,8 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *tw, in
             const int l = e / quads, q = e - l * quads;
             const int k = q & (half - 1);
             cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
-            const cplx w1 = twiddle2<INV, TWLDS>(tw, k * ts1);
-            const cplx w2 = twiddle2<INV, TWLDS>(tw, k * ts2), w3 = twiddle2<INV, TWLDS>(tw, (k + half) * ts2);
+            const cplx w1 = twiddle<INV>(tw, k * ts1);
+            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
             const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
             // stage s: (x0, x1) and (x2, x3), both with w1
             const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
@@ -454,11 +432,9 @@ __device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__res
 // it is allocated for it: the power-of-two kernels would drop from 8+ to 2 waves per SIMD (measured: 1 984 pairs of
 // 1024 x 256 in 57 instead of 29 ms)
 template <bool INV, bool BWD, bool GEN>
-__device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *tw, const AxisPlan &pl, int tid, int nt,
-                                               bool tw_in_lds = false) {
+__device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
     if (GEN && pl.nf) lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
-    else if (!GEN && tw_in_lds) lines_fft_pow2<INV, true>(base, pl.len, nlines, tw, tid, nt);
-    else lines_fft_pow2<INV, false>(base, pl.len, nlines, tw, tid, nt);
+    else lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
 }
 
 // Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
@@ -479,7 +455,7 @@ template <bool INV, bool BWD, bool GEN>
 __device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt) {
     const int n = X.n;
     if (!X.m) {
-        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt, X.tw_lds);
+        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt);
         return;
     }
     const int M = X.m;
@@ -693,10 +669,9 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
-    Axis X = axis_of(P, 1);
+    const Axis X = axis_of(P, 1);
     const int ld = X.ld;                           // line pitch: the Bluestein length when n1 needs one
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
-    if (!GEN) stage_twiddles(X, x + (int64_t)rl * ld, P.twl1 != 0, threadIdx.x, blockDim.x);
     const int pair = blockIdx.y, r0 = blockIdx.x * rl;
     const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
@@ -762,9 +737,8 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         f[(int64_t)c * n0 + r] = A[(int64_t)r * n1h + c0 + c];
         g[(int64_t)c * n0 + r] = B[(int64_t)r * n1h + c0 + c];
     }
-    Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
-    if (!GEN) stage_twiddles(X, g + (int64_t)tc * n0, P.twl0 != 0, tid, nt);
     __syncthreads();
+    const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
         lines_fft<false, false, GEN>(f, X, 2 * tc, tid, nt);
     } else {
@@ -944,10 +918,9 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
     const int nrp = (n0 + 1) / 2;
-    Axis X = axis_of(P, 1);
+    const Axis X = axis_of(P, 1);
     const int ld = X.ld;
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
-    if (!GEN) stage_twiddles(X, x + (int64_t)rl * ld, P.twl1 != 0, threadIdx.x, blockDim.x);
     const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
     const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1357,15 +1330,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.rl_fwd = rlf;
     P.rl_inv = rli;
     const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
-    size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
-    // a directly transformed power-of-two axis: the half twiddle table rides in LDS behind the lines where it fits
-    const size_t LDS_MAX = 160 * 1024 - 1024;
-    const size_t tw1_bytes = (size_t)L.n1 / 2 * 16, tw0_bytes = (size_t)L.n0 / 2 * 16;
-    P.twl1 = (!L.m1 && !L.ax1.nf && std::max(lds_fwd, lds_inv) + tw1_bytes <= LDS_MAX) ? 1 : 0;
-    if (P.twl1) {
-        lds_fwd += tw1_bytes;
-        lds_inv += tw1_bytes;
-    }
+    const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
     // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
     const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
 #define SQ_LAUNCH(KERNEL, GRID, THREADS, LDS)                                        \
@@ -1387,9 +1352,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
         else SQ_LAUNCH(columns_single_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
     } else {
-        size_t lds_col = (size_t)2 * tc * L.n0 * 16;
-        P.twl0 = (!L.ax0.nf && lds_col + tw0_bytes <= LDS_MAX) ? 1 : 0;
-        if (P.twl0) lds_col += tw0_bytes;
+        const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
         const dim3 grid_col((L.n1h + tc - 1) / tc, a->n_pairs);
         if (gen0) SQ_LAUNCH(columns_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
         else SQ_LAUNCH(columns_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
