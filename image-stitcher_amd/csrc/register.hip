@@ -665,7 +665,7 @@ __device__ __forceinline__ double normalised(const T *tile, int64_t idx, double 
 // the line FFT together: one barrier per pass for the batch, and eight times fewer, fuller blocks
 // than one row per block.
 template <typename T, bool GEN>
-__global__ __launch_bounds__(256) void rows_forward_kernel(RegParams P) {
+__global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
@@ -801,12 +801,12 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
 // column spectra F and G go back to the workspace between the three transforms instead of staying in LDS -- every
 // thread re-reads exactly the elements it wrote.
 template <bool GEN>
-__global__ __launch_bounds__(SQ_COL_THREADS) void columns_single_kernel(RegParams P) {
+__global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n0 = L.n0, n1h = L.n1h;
     cplx *x = reinterpret_cast<cplx *>(smem);   // [ld]
-    __shared__ double red[2][SQ_COL_THREADS / 64];
+    __shared__ double red[2][1024 / 64];
     const int pair = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
@@ -913,7 +913,7 @@ __device__ __forceinline__ Best wave_best(Best b) {
 }
 
 template <bool GEN>
-__global__ __launch_bounds__(256) void rows_inverse_kernel(RegParams P) {
+__global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
     const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
@@ -1329,7 +1329,14 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     const int rli = lines_per_block(8, (L.n0 + 1) / 2);
     P.rl_fwd = rlf;
     P.rl_inv = rli;
-    const int ntf = rlf > 1 ? 256 : pick_threads(L.n1), nti = rli > 1 ? 256 : pick_threads(L.n1);
+    // one LONG line per block (a Bluestein line of thousands of points: up to 152 KB of LDS, so one or two blocks per CU):
+    // the block brings the waves that hide its latencies itself -- 1024 threads from 32 KB of line on, 512 from 16 KB
+    // (measured on 312 x 3122 crops, lines of 6400 points: rows forward 2.87 -> see profiles/r03_kernel_probe_registration.log)
+    auto line_threads = [&](int rl) {
+        if (rl > 1) return 256;
+        return line_bytes >= 32 * 1024 ? 1024 : (line_bytes >= 16 * 1024 ? 512 : pick_threads(L.n1));
+    };
+    const int ntf = line_threads(rlf), nti = line_threads(rli);
     const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
     // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
     const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
@@ -1349,8 +1356,9 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     if (tc < 1) {
         const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
         const dim3 grid_col(L.n1h, a->n_pairs);
-        if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
-        else SQ_LAUNCH(columns_single_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
+        const int ntc = lds_col > 80 * 1024 ? 1024 : SQ_COL_THREADS;     // one block per CU: twice the waves
+        if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, ntc, lds_col);
+        else SQ_LAUNCH(columns_single_kernel<false>, grid_col, ntc, lds_col);
     } else {
         const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
         const dim3 grid_col((L.n1h + tc - 1) / tc, a->n_pairs);

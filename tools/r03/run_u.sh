@@ -17,7 +17,8 @@ for r in rows:
         cur = {}
         calls.append(cur)
     if cur is not None and 'anonymous' in n:
-        short = n.split('::')[-1].split('(')[0]
+        import re
+        short = re.search(r'(\w+_kernel)', n).group(1)
         cur[short] = cur.get(short, 0) + (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 for i, c in enumerate(calls):
     print(i, ' '.join(f'{k}={v:.0f}us' for k, v in c.items()))
