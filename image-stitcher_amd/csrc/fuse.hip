@@ -805,11 +805,17 @@ __device__ __forceinline__ void load_gains(const char *p, double (&g)[8]) {
 // in which a bare copy gains 10 %, was built and measured with groups of 5 / 3 / 2: 0.53 / 0.43 / 0.39 against 0.62-0.64
 // for this form on the same box; the descriptor, its LDS hand-over and the tile pointers cost more per 14-36 KB workgroup
 // than the access pattern gives back.  profiles/r02_exp20_row_per_workgroup.log)
+// G = NoGain: planes WITHOUT a flatfield carried through an item together -- nothing is shared between them but the
+// geometry, yet five planes per thread write faster than one plane per launch when the planes lie in different stretches
+// of device memory (DESIGN.md 5.1 point 9: the bare 5-plane copy 0.72-0.75 of peak against 0.64-0.65 plane by plane)
+struct NoGain {};
 template <bool FULL, int RND = 0, typename G = float>
 __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
                                                 const int wave, const int lane) {
     typedef uint16_t T;
-    constexpr uint32_t GSZ = sizeof(G);
+    constexpr bool GAINS = !std::is_same<G, NoGain>::value;
+    typedef typename std::conditional<GAINS, G, float>::type GT;      // the arithmetic type where there is arithmetic
+    constexpr uint32_t GSZ = sizeof(GT);
     constexpr int VEC = 8, LINE = 64;
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
@@ -834,15 +840,20 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                 const bool left = p < 0;
                 const int po = left ? p : -1;
                 const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
-                const G *lflat = static_cast<const G *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
-                const G eg = ldg_s<G>(reinterpret_cast<const char *>(lflat + (int64_t)(sb + r) * P.tile_w + sc) + po * (int)GSZ);
-                const G er = recip_of<RND>(eg);
+                GT eg = GT(1), er = GT(1);
+                if constexpr (GAINS) {
+                    const GT *lflat = static_cast<const GT *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+                    eg = ldg_s<GT>(reinterpret_cast<const char *>(lflat + (int64_t)(sb + r) * P.tile_w + sc) + po * (int)GSZ);
+                    er = recip_of<RND>(eg);
+                }
 #pragma unroll
                 for (int z = 0; z < ZB; ++z)
                     if (FULL || z < gn) {
                         const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
                         const T e = ldg_s<T>(reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc) + po * 2);
-                        const uint32_t kq = left ? min(cvt_u32_sat(quot_of<RND>((G)e, eg, er)), 65535u) : 0u;
+                        uint32_t kq = e;
+                        if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e, eg, er)), 65535u);
+                        if (!left) kq = 0u;
                         stg_s<T>(reinterpret_cast<char *>(cplane[z] + doff) + p * 2, (T)kq);
                     }
             }
@@ -857,13 +868,14 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         }
         return;
     }
-    const G *flat = static_cast<const G *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
+    const GT *flat = nullptr;
+    if constexpr (GAINS) flat = static_cast<const GT *>(P.flat_ptrs[sgpr(A.g.plane[0])]);
     for (int r = wave; r < rows; r += 4) {
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
         const int64_t soff = (int64_t)(it.b + r) * P.tile_pitch + it.c;
         // row bases are wave-uniform (scalar registers); a lane adds ONE 32-bit byte offset, shared by the planes, so the
         // loads and stores take the scalar-base + vector-offset form and no 64-bit address pair per plane lives in VGPRs
-        const char *frow = reinterpret_cast<const char *>(flat + (int64_t)(it.b + r) * P.tile_w + it.c);
+        const char *frow = GAINS ? reinterpret_cast<const char *>(flat + (int64_t)(it.b + r) * P.tile_w + it.c) : nullptr;
         const char *srow[ZB];
         char *drow[ZB];
 #pragma unroll
@@ -885,20 +897,24 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             const bool act = v >= v_first && v < v_end;
             const int p0 = v * VEC - mis;
             const uint32_t o = (uint32_t)min(max(p0, 0), n - VEC);   // clamped: v_end > v_first implies n >= VEC; == p0 where act
-            G g[8], rc[8];
-            load_gains(frow + o * GSZ, g);
+            GT g[8], rc[8];
+            if constexpr (GAINS) load_gains(frow + o * GSZ, g);
             u32x4 px[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) px[z] = ldg<U32x4U>(srow[z] + o * 2u);
+            if constexpr (GAINS) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rc[c] = recip_of<RND>(g[c]);
+                for (int c = 0; c < 8; ++c) rc[c] = recip_of<RND>(g[c]);
+            }
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    u32x4 ov;
+                    u32x4 ov = px[z];
+                    if constexpr (GAINS) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ov[c] = quot_pair<RND, G>(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                        for (int c = 0; c < 4; ++c) ov[c] = quot_pair<RND, GT>(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                    }
                     if (act) stg_nt_at(drow[z], o * 2u, ov);
                 }
         }
@@ -909,8 +925,11 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             const bool left = p < 0, lzero = sflags & SEAM_LEFT_ZERO;
             const int sb = sgpr(A.seam.b), sc = sgpr(A.seam.c);
             const int po = (left && lzero) ? 0 : p;   // left of a zero-fill seam: any valid address, the value is replaced
-            const char *lfrow = lzero ? frow : reinterpret_cast<const char *>(flat + (int64_t)(sb + r) * P.tile_w + sc);
-            const G eg = ldg_s<G>((left ? lfrow : frow) + po * (int)GSZ);
+            GT eg = GT(1), er = GT(1);
+            if constexpr (GAINS) {
+                const char *lfrow = lzero ? frow : reinterpret_cast<const char *>(flat + (int64_t)(sb + r) * P.tile_w + sc);
+                eg = ldg_s<GT>((left ? lfrow : frow) + po * (int)GSZ);
+            }
             T e[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
@@ -919,11 +938,12 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                     const char *lrow = lzero ? srow[z] : reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc);
                     e[z] = ldg_s<T>((left ? lrow : srow[z]) + po * 2);
                 }
-            const G er = recip_of<RND>(eg);
+            if constexpr (GAINS) er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    uint32_t kq = min(cvt_u32_sat(quot_of<RND>((G)e[z], eg, er)), 65535u);
+                    uint32_t kq = e[z];
+                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), 65535u);
                     if (left && lzero) kq = 0;
                     stg_s<T>(drow[z] + p * 2, (T)kq);
                 }
@@ -941,16 +961,18 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
         }
         if (__builtin_amdgcn_ballot_w64(ep >= 0)) {   // wave-uniform: many rows have no edge pixels at all
             const uint32_t eo = (uint32_t)max(ep, 0);
-            const G eg = ldg_s<G>(frow + eo * GSZ);
+            GT eg = GT(1), er = GT(1);
+            if constexpr (GAINS) eg = ldg_s<GT>(frow + eo * GSZ);
             T e[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) e[z] = ldg_s<T>(srow[z] + eo * 2u);
-            const G er = recip_of<RND>(eg);
+            if constexpr (GAINS) er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
-                    const uint32_t kq = min(cvt_u32_sat(quot_of<RND>((G)e[z], eg, er)), 65535u);
+                    uint32_t kq = e[z];
+                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), 65535u);
                     if (ep >= 0) stg_s<T>(drow[z] + eo * 2u, (T)kq);
                 }
         }
@@ -963,7 +985,7 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
 template <typename G, bool DYN>
 __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(const FuseParams P, const int64_t n_items) {
     typedef uint16_t T;
-    constexpr int FLAT = sizeof(G) == 8 ? 2 : 1;
+    constexpr int FLAT = std::is_same<G, NoGain>::value ? 0 : (sizeof(G) == 8 ? 2 : 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = *P.n_groups;
@@ -1883,6 +1905,20 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             }
             if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<float, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
             return launch_zg(fuse_overwrite_zg_kernel<float, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        }
+        if (u16 && !flat && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
+            // no flatfield: the planes still go through the items ZB at a time, dealt over the canvas allocation -- they
+            // share nothing but the geometry, but a group's stores land in different stretches of device memory
+            char *sc = static_cast<char *>(a->scratch_dev);
+            uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
+            PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
+            hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, (const void *const *)nullptr, (const uint32_t *)nullptr, 0u,
+                               a->n_planes, a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                               (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
+            P.groups = groups;
+            P.n_groups = n_groups;
+            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<NoGain, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            return launch_zg(fuse_overwrite_zg_kernel<NoGain, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
         }
         if (u16) {
             if (flat == 0) SQ_OVERWRITE(uint16_t, 0);

@@ -17,6 +17,7 @@ g = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 Z = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+nogain = len(sys.argv) > 5 and sys.argv[5] == 'nogain'     # planes WITHOUT a flatfield: grouped (round 3) against plane by plane
 P, T = C * Z, 2048
 dev = torch.device('cuda:0')
 spec, truth, wc, hc, xs, ys, order, order_rc = bench.grid_setup(g, 3000)
@@ -27,7 +28,7 @@ for p in range(P):
     native.synth_tiles(bench.plane_desc(spec, g, p // Z, p % Z), T, T, spec.noise, 'uint16', dev, out=tiles[p])
 canvas = native.empty_canvas(P, hc, wc, torch.uint16, dev)
 ffs = [torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32) * np.float32(1 + 0.03125 * c)).to(dev) for c in range(C)]
-alg = bench.algorithmic_bytes(P, plan.covered_voxels, hc, wc, True)
+alg = bench.algorithmic_bytes(P, plan.covered_voxels, hc, wc, not nogain)
 tile_order = torch.tensor(order, dtype=torch.int64)
 print(f'{P} planes ({C} gain images x {Z}) of the {g}x{g} grid, canvas {hc}x{wc}: {P * canvas.stride(0) * 2 / 2**30:.1f} GiB of canvas, '
       f'{tiles.numel() * 2 / 2**30:.1f} GiB of tiles', flush=True)
@@ -46,7 +47,7 @@ def run(cfg, flags, reps=3):
     for _ in range(reps + 1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        native.fuse_planes(plan, None, canvas, flats, tile_ptrs=ptrs, flat_ptrs=fp, flags=flags)
+        native.fuse_planes(plan, None, canvas, None if nogain else flats, tile_ptrs=ptrs, flat_ptrs=None if nogain else fp, flags=flags)
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
@@ -63,10 +64,10 @@ cfgs = {name: setup(name) for name in ('plane', 'spread')}
 want = None
 for r in range(rounds):
     for name in ('plane', 'spread'):
-        for gname, flags in (('consecutive', native.SQ_FUSE_CONSECUTIVE_GROUPS), ('dealt', 0)):
+        for gname, flags in ((('one plane at a time', native.SQ_FUSE_NO_PLANE_GROUPS),) if nogain else ()) + (('consecutive', native.SQ_FUSE_CONSECUTIVE_GROUPS), ('dealt', 0)):
             ms = run(cfgs[name], flags)
             d = digest(cfgs[name])
             want = want or d
             assert d == want, 'the fused planes differ between the variants'
-            print(f'round {r}: slots {name:6s} groups {gname:11s}  {ms:7.3f} ms   {alg / ms / 1e6 / 8000:.4f} of 8 TB/s', flush=True)
+            print(f'round {r}: slots {name:6s} groups {gname:19s}  {ms:7.3f} ms   {alg / ms / 1e6 / 8000:.4f} of 8 TB/s', flush=True)
 print('every variant produced the same planes (digests of planes 0, Z-1, P-1)')
