@@ -214,6 +214,28 @@ def _pair_table_worker(rank, world, port, out_dir):
             np.testing.assert_array_equal(table, full)                      # bit for bit, pair order, on every rank
         with pytest.raises(ValueError):
             sh.all_gather_pair_table(np.zeros((1, 3)), 1984, rank, world)   # not this rank's run
+        # the whole sharded registration with the device step replaced by a stand-in (no GPU here): every rank loads
+        # exactly the cells its run of pairs touches, registers exactly its run, and ends with the complete table
+        from image_stitcher_amd import registration as R
+        pairs = R.grid_pair_list(5, 4)
+        seen = {}
+
+        def fake_subset(tiles, local_index, prs, indices, h, w, mx, my, normalization='phase', minmax=None):
+            assert prs is pairs and list(indices) == R.pairs_of_rank(len(pairs), rank, world)
+            assert set(local_index) == set(seen['cells']) and len(tiles) == len(seen['cells'])
+            return np.array([[i + 0.5, -i, 0.001 * i] for i in indices], dtype=np.float64).reshape(-1, 3)
+
+        def load_cells(cells):
+            seen['cells'] = list(cells)
+            return list(cells)
+        real = R.register_pair_subset
+        R.register_pair_subset = fake_subset
+        try:
+            table = R.register_all_pairs_sharded(pairs, load_cells, 64, 64, 16, 16, 'phase', rank=rank, world=world)
+        finally:
+            R.register_pair_subset = real
+        np.testing.assert_array_equal(table, np.array([[i + 0.5, -i, 0.001 * i] for i in range(len(pairs))]))
+        assert seen['cells'] == R.cells_of_pairs(pairs, R.pairs_of_rank(len(pairs), rank, world)) and len(seen['cells']) < 20
         open(os.path.join(out_dir, f'pairs_ok{rank}'), 'w').close()
     finally:
         dist.destroy_process_group()

@@ -64,10 +64,11 @@ cfgs = {name: setup(name) for name in ('plane', 'spread')}
 want = None
 for r in range(rounds):
     for name in ('plane', 'spread'):
-        for gname, flags in ((('one plane at a time', native.SQ_FUSE_NO_PLANE_GROUPS),) if nogain else ()) + (('consecutive', native.SQ_FUSE_CONSECUTIVE_GROUPS), ('dealt', 0)):
+        extra = (('consecutive, unit-minor walk', native.SQ_FUSE_CONSECUTIVE_GROUPS | 32), ('dealt, unit-minor walk', 32)) if os.environ.get('SQ_PROBE_UNIT_MINOR') else ()
+        for gname, flags in ((('one plane at a time', native.SQ_FUSE_NO_PLANE_GROUPS),) if nogain else ()) + (('consecutive', native.SQ_FUSE_CONSECUTIVE_GROUPS), ('dealt', 0)) + extra:
             ms = run(cfgs[name], flags)
             d = digest(cfgs[name])
             want = want or d
             assert d == want, 'the fused planes differ between the variants'
-            print(f'round {r}: slots {name:6s} groups {gname:19s}  {ms:7.3f} ms   {alg / ms / 1e6 / 8000:.4f} of 8 TB/s', flush=True)
+            print(f'round {r}: slots {name:6s} groups {gname:28s}  {ms:7.3f} ms   {alg / ms / 1e6 / 8000:.4f} of 8 TB/s', flush=True)
 print('every variant produced the same planes (digests of planes 0, Z-1, P-1)')
