@@ -82,6 +82,9 @@ def main():
                     help="region workloads: where a (c, z) plane's canvas sits in the canvas allocation.  'spread' (default): "
                          "z-major, so that the z planes of a channel -- which go through the kernel together -- lie a channel "
                          "count of planes apart, spread over the whole allocation; 'plane': plane p = c * Z + z at slot p")
+    ap.add_argument('--layout', choices=['arena', 'separate'], default='arena',
+                    help="'arena' (default): canvas slots and tile stacks interleaved in ONE allocation, so that the canvas planes "
+                         "are spread over all the memory the job holds; 'separate': one allocation each (round 2)")
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
@@ -215,6 +218,35 @@ def plane_digest(plane, rows_per_chunk=2048):
     return d
 
 
+def alloc_planes(n, g, hc, wc, dev, layout):
+    """Tile stacks [n, g*g, TILE, TILE] and canvas slots [n, hc, wc] (uint16) for n planes.
+    'arena': ONE allocation [canvas slot 0 | tile stack 0 | canvas slot 1 | tile stack 1 | ...]: the canvas slots then lie
+    (canvas plane + tile stack) bytes apart, spread over all the memory the job holds, instead of side by side in an
+    allocation of their own -- the planes of a group write fastest when they lie in different stretches of device memory
+    (DESIGN.md 5.1 point 9), and this doubles the distance between them.  Both are views the library takes as they are:
+    a canvas at any plane stride (a multiple of 128 bytes keeps the plane groups), tiles by pointer table.
+    'separate': round 2's two allocations."""
+    import torch
+    from image_stitcher_amd import native
+    if layout != 'arena':
+        return torch.empty((n, g * g, TILE, TILE), dtype=torch.uint16, device=dev), native.empty_canvas(n, hc, wc, torch.uint16, dev)
+    cplane = -(-(hc * wc * 2) // 4096) * 4096
+    tplane = g * g * TILE * TILE * 2
+    arena = torch.empty(n * (cplane + tplane), dtype=torch.uint8, device=dev).view(torch.uint16)
+    stride = (cplane + tplane) // 2
+    canvas = arena.as_strided((n, hc, wc), (stride, wc, 1))
+    tiles = arena.as_strided((n, g * g, TILE, TILE), (stride, TILE * TILE, TILE, 1), storage_offset=cplane // 2)
+    return tiles, canvas
+
+
+def tile_pointer_table(tiles, planes, tile_order, dev):
+    """int64 device table [len(planes) * tiles per plane]: pointer of tile tile_order[i] of tile stack planes[k] at k * T + i."""
+    import torch
+    esz = TILE * TILE * 2
+    ptrs = tiles.data_ptr() + torch.as_tensor(list(planes), dtype=torch.int64)[:, None] * (tiles.stride(0) * 2) + tile_order[None, :] * esz
+    return ptrs.reshape(-1).to(dev)
+
+
 def algorithmic_bytes(n_planes, covered, hc, wc, flat):
     # SURVEY 8(d): 4 B per covered voxel (2 B read + 2 B write), 2 B per uncovered voxel (zero write),
     # + the float32 flatfield once per plane
@@ -262,7 +294,7 @@ def run_region(ctx):
     n_planes = C_eff * Z_eff
 
     # ---- resident inputs: tiles generated on the device (not timed) -------------------------
-    tiles = torch.empty((n_planes, g * g, TILE, TILE), dtype=torch.uint16, device=dev)
+    tiles, canvas = alloc_planes(n_planes, g, hc, wc, dev, args.layout)
     for p in range(n_planes):
         c, z = divmod(p, Z_eff)
         native.synth_tiles(plane_desc(spec, g, c, z), TILE, TILE, spec.noise, 'uint16', dev, out=tiles[p])
@@ -284,15 +316,11 @@ def run_region(ctx):
     slot_of_plane = {p: s for s, p in enumerate(plane_of_slot)}
     slot_flats = [flat_list[p] for p in plane_of_slot] if flat_list else None
     flat_ptrs = native.pointer_table(slot_flats, dev) if slot_flats else None
-    # dense rows like the reference's array; every plane starts on a 128-byte line (native.empty_canvas)
-    canvas = native.empty_canvas(n_planes, hc, wc, torch.uint16, dev)
+    # canvas: dense rows like the reference's array; every plane starts on a 128-byte line (alloc_planes)
     canvas_of_plane = [canvas[slot_of_plane[p]] for p in range(n_planes)]
     tile_order = torch.tensor(order, dtype=torch.int64)
     # tile pointer table in write order (slot-major), so rect i <-> pointer i
-    esz = TILE * TILE * 2
-    base = tiles.data_ptr()
-    ptrs = (base + (torch.tensor(plane_of_slot, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
-    ptrs = ptrs.reshape(-1).to(dev)
+    ptrs = tile_pointer_table(tiles, plane_of_slot, tile_order, dev)
     reg_plane = tiles[0]   # registration channel = first channel, z level 0 (CLI defaults)
     torch.cuda.synchronize()
 
@@ -401,7 +429,7 @@ def run_region(ctx):
         'scaling': 'weak' if (world > 1 and args.weak) else 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'config': {'workload': wl['desc'], 'planes_resident_per_gpu': n_planes,
-                   'canvas': [hc, wc], 'tiles_per_plane': g * g, 'canvas_order': args.canvas_order,
+                   'canvas': [hc, wc], 'tiles_per_plane': g * g, 'canvas_order': args.canvas_order, 'layout': args.layout,
                    'parallelism': f'one region per GPU x{world}, shift-table all-gather' if world > 1 else 'single GPU',
                    'shifts': {'h': list(state['shifts'].h_shift), 'v': list(state['shifts'].v_shift)},
                    'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes; the next '
@@ -528,15 +556,12 @@ def run_job(ctx):
     batches = [mine[i:i + cap] for i in range(0, len(mine), cap)]
     bmax = max((len(b) for b in batches), default=1)
 
-    tiles = torch.empty((bmax, g * g, TILE, TILE), dtype=torch.uint16, device=dev)
-    canvas = native.empty_canvas(bmax, hc, wc, torch.uint16, dev)
+    tiles, canvas = alloc_planes(bmax, g, hc, wc, dev, args.layout)
     ffs = [torch.from_numpy(synth.synthetic_flatfield(TILE, TILE, np.float32) * np.float32(1 + 0.03125 * c)).to(dev)
            for c in range(C)]
     descs = {p: plane_desc(spec, g, p // Z, p % Z) for p in mine}
     tile_order = torch.tensor(order, dtype=torch.int64)
-    esz = TILE * TILE * 2
-    ptrs_all = (tiles.data_ptr() + (torch.arange(bmax, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * esz)
-    ptrs_all = ptrs_all.reshape(-1).to(dev)
+    ptrs_all = tile_pointer_table(tiles, range(bmax), tile_order, dev)
     flat_tables = [native.pointer_table([ffs[p // Z] for p in b], dev) for b in batches]
     # Registration inputs, resident before the timed region like every other input.
     #   default: ALL adjacent pairs of the registration plane (channel 0, z 0), dealt over the ranks in contiguous runs
@@ -692,7 +717,7 @@ def run_job(ctx):
                                     f'({len(my_pairs)} pairs / {len(reg_cells)} resident tiles on rank 0), [n_pairs, 3] float64 table '
                                     'all-gathered, per-axis median') if all_pairs else
                                    "the reference's centre pairs on rank 0 (stitcher.py:455-485), 8-int32 row all-gathered",
-                   'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g,
+                   'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g, 'layout': args.layout,
                    'parallelism': f'planes dealt over {world} GPUs in contiguous runs (a channel\'s z planes stay together), rank 0 registers, '
                                   f'shift row all-gathered over {"RCCL" if ctx["backend"] == "nccl" else ctx["backend"]}, no image data exchanged',
                    'shifts': {'h': list(shifts.h_shift), 'v': list(shifts.v_shift)},
@@ -726,7 +751,7 @@ def cpu_baseline_fusion_only(tiles, flat_list, order, spec, xs, ys, g, hc, wc, t
     device registration was checked against) on a bounded sample, compared with the GPU canvas."""
     from oracle import stitch_oracle as O
     n = min(max_planes, tiles.shape[0])
-    host = tiles[:n].cpu().numpy()
+    host = np.stack([tiles[p].cpu().numpy() for p in range(n)])      # plane by plane: the stacks may be views of an arena
     t0 = time.perf_counter()
     rects = oracle_rects(O, g, xs, ys, truth.h_shift, truth.v_shift, order, spec, hc, wc)
     voxels = mismatched = 0

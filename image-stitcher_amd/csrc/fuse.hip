@@ -101,7 +101,6 @@ struct FuseParams {
     int32_t chunk;                // consecutive lane positions a workgroup takes per atomic, 1..QUEUE_CHUNK
     const struct PlaneGroup *groups;   // plane groups of the float32-gain kernel (build_groups_kernel), else NULL
     const uint32_t *n_groups;          // how many there are (device side: the host never learns it)
-    int32_t unit_minor;                // queue walk: 1 = units (planes / groups) vary fastest, items slowest (experiment)
 };
 // Planes that are divided by the SAME gain image (the z planes of a channel) and whose canvas rows sit at the same
 // phase inside a 128-byte line are carried through an item together: the gains and their reciprocals are loaded /
@@ -636,9 +635,12 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
         if ((int)threadIdx.x < count) {   // one descriptor per thread: queue position -> (plane, list position)
             const uint32_t per_plane = per_plane_of(q);
             const uint32_t u = u0 + threadIdx.x;
-            // unit-major (default): all items of unit 0, then unit 1 ...; unit-minor: position r of every unit, then r + 1
-            const int plane = P.unit_minor ? (int)(u % n_units) : (int)(u / per_plane);
-            const uint32_t r = P.unit_minor ? u / n_units : u - (uint32_t)plane * per_plane;
+            // (unit-major: all items of unit 0, then unit 1 ...  The other way round -- position r of every unit, then r + 1,
+            // so that the chip writes into ALL groups' planes at once -- was measured in round 3: 0.680 whatever the grouping,
+            // between consecutive groups (0.647) and spread + dealt ones (0.692) on the same buffers;
+            // profiles/r03_exp_unit_minor_*.log)
+            const int plane = (int)(u / per_plane);
+            const uint32_t r = u - (uint32_t)plane * per_plane;
             const int64_t pos = q < 8 ? (int64_t)r * 8 + q : 8 * (int64_t)P.lane_items + r;
             const Item it = P.items[pos];
             s_item[threadIdx.x] = it;
@@ -1815,7 +1817,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (a->tile_pitch < a->tile_w || a->canvas_pitch < a->canvas_w)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: pitch smaller than width");
     if (a->n_planes < 0) return fail(SQ_ERR_INVALID, "sq_fuse_planes: n_planes %d out of range", a->n_planes);
-    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS | SQ_FUSE_NO_SEAM_OWNERS | SQ_FUSE_CONSECUTIVE_GROUPS | 32)) || a->grid_blocks < 0 ||
+    if ((a->flags & ~(SQ_FUSE_FORCE_QUEUES | SQ_FUSE_FORCE_STATIC | SQ_FUSE_NO_PLANE_GROUPS | SQ_FUSE_NO_SEAM_OWNERS | SQ_FUSE_CONSECUTIVE_GROUPS)) || a->grid_blocks < 0 ||
         ((a->flags & SQ_FUSE_FORCE_QUEUES) && (a->flags & SQ_FUSE_FORCE_STATIC)))
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: flags %d / grid_blocks %d", a->flags, a->grid_blocks);
     if (a->tile_dtype != SQ_U8 && a->tile_dtype != SQ_U16)
@@ -1847,7 +1849,6 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     P.tile_pitch = a->tile_pitch;
     P.canvas_pitch = a->canvas_pitch;
     P.flat_class = nullptr;
-    P.unit_minor = (a->flags & 32) ? 1 : 0;   // (experiment flag, not in the header: see profiles/r03_exp_unit_minor.log)
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int flat = a->flat_ptrs_dev ? (a->flat_dtype == SQ_F64 ? 2 : 1) : 0;
     P.queue = nullptr;

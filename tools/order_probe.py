@@ -23,21 +23,32 @@ dev = torch.device('cuda:0')
 spec, truth, wc, hc, xs, ys, order, order_rc = bench.grid_setup(g, 3000)
 rects = placement.grid_rects(g, g, T, T, truth, order=order_rc)
 plan = native.FusePlan(rects, T, T, hc, wc, native.SQ_FUSE_OVERWRITE)
-tiles = torch.empty((P, g * g, T, T), dtype=torch.uint16, device=dev)
+# SQ_PROBE_LAYOUT=interleaved: ONE arena [canvas slot 0 | tile stack 0 | canvas slot 1 | tile stack 1 | ...] -- the canvas
+# planes then lie (canvas plane + tile stack) bytes apart, over all the memory the job holds, instead of side by side
+interleaved = os.environ.get('SQ_PROBE_LAYOUT') == 'interleaved'
+if interleaved:
+    cplane = -(-(hc * wc * 2) // 4096) * 4096
+    tplane = g * g * T * T * 2
+    arena = torch.empty(P * (cplane + tplane), dtype=torch.uint8, device=dev)
+    canvas = arena.view(torch.uint16).as_strided((P, hc, wc), ((cplane + tplane) // 2, wc, 1))
+    tiles = arena.view(torch.uint16).as_strided((P, g * g, T, T), ((cplane + tplane) // 2, T * T, T, 1), storage_offset=cplane // 2)
+else:
+    tiles = torch.empty((P, g * g, T, T), dtype=torch.uint16, device=dev)
+    canvas = native.empty_canvas(P, hc, wc, torch.uint16, dev)
 for p in range(P):
     native.synth_tiles(bench.plane_desc(spec, g, p // Z, p % Z), T, T, spec.noise, 'uint16', dev, out=tiles[p])
-canvas = native.empty_canvas(P, hc, wc, torch.uint16, dev)
 ffs = [torch.from_numpy(synth.synthetic_flatfield(T, T, np.float32) * np.float32(1 + 0.03125 * c)).to(dev) for c in range(C)]
 alg = bench.algorithmic_bytes(P, plan.covered_voxels, hc, wc, not nogain)
 tile_order = torch.tensor(order, dtype=torch.int64)
-print(f'{P} planes ({C} gain images x {Z}) of the {g}x{g} grid, canvas {hc}x{wc}: {P * canvas.stride(0) * 2 / 2**30:.1f} GiB of canvas, '
+print(f'{P} planes ({C} gain images x {Z}) of the {g}x{g} grid, canvas {hc}x{wc}: canvas planes {canvas.stride(0) * 2 / 2**30:.2f} GiB apart '
+      f'({"one arena, canvas slots and tile stacks interleaved" if interleaved else "canvas and tiles in two allocations"}), '
       f'{tiles.numel() * 2 / 2**30:.1f} GiB of tiles', flush=True)
 
 
 def setup(slot_order):
     plane_of_slot = [(s % C) * Z + s // C for s in range(P)] if slot_order == 'spread' else list(range(P))
     flats = [ffs[p // Z] for p in plane_of_slot]
-    ptrs = (tiles.data_ptr() + (torch.tensor(plane_of_slot, dtype=torch.int64)[:, None] * (g * g) + tile_order[None, :]) * (T * T * 2))
+    ptrs = (tiles.data_ptr() + torch.tensor(plane_of_slot, dtype=torch.int64)[:, None] * (tiles.stride(0) * 2) + tile_order[None, :] * (T * T * 2))
     return plane_of_slot, flats, native.pointer_table(flats, dev), ptrs.reshape(-1).to(dev)
 
 
@@ -64,7 +75,7 @@ cfgs = {name: setup(name) for name in ('plane', 'spread')}
 want = None
 for r in range(rounds):
     for name in ('plane', 'spread'):
-        extra = (('consecutive, unit-minor walk', native.SQ_FUSE_CONSECUTIVE_GROUPS | 32), ('dealt, unit-minor walk', 32)) if os.environ.get('SQ_PROBE_UNIT_MINOR') else ()
+        extra = ()
         for gname, flags in ((('one plane at a time', native.SQ_FUSE_NO_PLANE_GROUPS),) if nogain else ()) + (('consecutive', native.SQ_FUSE_CONSECUTIVE_GROUPS), ('dealt', 0)) + extra:
             ms = run(cfgs[name], flags)
             d = digest(cfgs[name])
