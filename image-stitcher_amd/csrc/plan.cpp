@@ -160,17 +160,12 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     std::vector<int> by_y0(cl.size());
     for (size_t i = 0; i < cl.size(); ++i) by_y0[i] = (int)i;
     std::stable_sort(by_y0.begin(), by_y0.end(), [&](int a, int b) { return cl[a].y0 < cl[b].y0; });
-    size_t next = 0;
-    std::vector<int> active;  // indices into cl, ascending (= write order)
-
     std::vector<Span> spans;
     std::vector<Ref> refs;
     int max_refs = 0;
     int64_t covered = 0;
 
-    // spans of the previous band that may continue into this one, sorted by xa (they are produced
-    // left to right); the current band's intervals are produced left to right too, so matching a
-    // continuation is a two-pointer walk.  Owner lists are small fixed arrays: no heap traffic per interval.
+    // Owner lists are small fixed arrays: no heap traffic per interval.
     struct Owners {
         int n = 0;
         int v[MAX_REFS];
@@ -181,113 +176,158 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
             return true;
         }
     };
+    // Phase 1, band by band and independent per band (a few threads take contiguous ranges of bands): the band's RUNS --
+    // maximal x intervals with one owner list, left to right.  A 32x32 grid has 2 049 bands of ~65 runs.
+    struct Run {
+        int xa, xb;
+        Owners own;
+    };
+    const size_t n_bands = ys.size() - 1;
+    const int hw_sweep = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const int sweep_threads = n_bands >= 512 ? hw_sweep : 1;
+    std::vector<std::vector<Run>> runs_of(sweep_threads);           // per thread: the runs of its bands, band after band
+    std::vector<std::vector<uint32_t>> run_end(sweep_threads);      // per thread: end of each of its bands in runs_of
+    std::vector<size_t> first_band(sweep_threads + 1, 0);
+    std::vector<int> overflow_at(sweep_threads, -1);                // feather: a band where more than MAX_REFS tiles overlap
+    std::vector<int> overflow_x(sweep_threads, 0);
+    parallel_ranges(sweep_threads, n_bands, [&](int t, size_t b_lo, size_t b_hi) {
+        first_band[t] = b_lo;
+        if (t + 1 == sweep_threads) first_band[t + 1] = n_bands;
+        std::vector<Run> &out = runs_of[t];
+        std::vector<uint32_t> &ends = run_end[t];
+        out.reserve((b_hi - b_lo) * 72);
+        ends.reserve(b_hi - b_lo);
+        if (b_lo >= b_hi) return;
+        // the active set at the range's first band: rects with y0 <= ya < y1, ascending (= write order) -- what the
+        // band-by-band updates below keep
+        std::vector<int> active;
+        const int y_first = ys[b_lo];
+        for (size_t i = 0; i < cl.size(); ++i)
+            if (cl[i].y0 <= y_first && cl[i].y1 > y_first) active.push_back((int)i);
+        size_t next = (size_t)(std::upper_bound(by_y0.begin(), by_y0.end(), y_first, [&](int y, int i) { return y < cl[i].y0; }) - by_y0.begin());
+        std::vector<int> xs, owner_of, skip;
+        for (size_t b = b_lo; b < b_hi; ++b) {
+            const int ya = ys[b];
+            while (next < by_y0.size() && cl[by_y0[next]].y0 <= ya) {
+                active.insert(std::upper_bound(active.begin(), active.end(), by_y0[next]), by_y0[next]);
+                ++next;
+            }
+            active.erase(std::remove_if(active.begin(), active.end(), [&](int i) { return cl[i].y1 <= ya; }), active.end());
+
+            xs.clear();
+            xs.push_back(0);
+            xs.push_back(canvas_w);
+            for (int i : active) {
+                xs.push_back(cl[i].x0);
+                xs.push_back(cl[i].x1);
+            }
+            std::sort(xs.begin(), xs.end());
+            xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+            const size_t m = xs.size() - 1;   // elementary x intervals of this band
+            if (mode == SQ_FUSE_OVERWRITE) {
+                // last writer wins: paint the intervals from the last active rect to the first, each interval
+                // once (skip pointers jump over what is already painted)
+                owner_of.assign(m, -1);
+                skip.resize(m + 1);
+                for (size_t k = 0; k <= m; ++k) skip[k] = (int)k;
+                auto find = [&](int k) {
+                    while (skip[k] != k) k = skip[k] = skip[skip[k]];
+                    return k;
+                };
+                for (size_t a = active.size(); a-- > 0;) {
+                    const Clipped &c = cl[active[a]];
+                    const int lo = (int)(std::lower_bound(xs.begin(), xs.end(), c.x0) - xs.begin());
+                    const int hi = (int)(std::lower_bound(xs.begin(), xs.end(), c.x1) - xs.begin());
+                    for (int k = find(lo); k < hi; k = find(k + 1)) {
+                        owner_of[k] = active[a];
+                        skip[k] = k + 1;
+                    }
+                }
+            }
+            bool have = false;
+            Run cur{};
+            for (size_t k = 0; k < m; ++k) {
+                const int xa = xs[k], xb = xs[k + 1];
+                Owners own;
+                if (mode == SQ_FUSE_OVERWRITE) {
+                    if (owner_of[k] >= 0) own.v[own.n++] = owner_of[k];
+                } else {
+                    for (int i : active)
+                        if (cl[i].x0 <= xa && cl[i].x1 >= xb) {
+                            if (own.n == MAX_REFS) {
+                                if (overflow_at[t] < 0) {
+                                    overflow_at[t] = ya;
+                                    overflow_x[t] = xa;
+                                }
+                                break;
+                            }
+                            own.v[own.n++] = i;
+                        }
+                }
+                if (have && cur.own == own && cur.xb == xa) {
+                    cur.xb = xb;
+                } else {
+                    if (have) out.push_back(cur);
+                    cur.xa = xa;
+                    cur.xb = xb;
+                    cur.own = own;
+                    have = true;
+                }
+            }
+            if (have) out.push_back(cur);
+            ends.push_back((uint32_t)out.size());
+        }
+    });
+    for (int t = 0; t < sweep_threads; ++t)
+        if (overflow_at[t] >= 0) {
+            fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: more than %d tiles overlap at canvas (%d,%d)", MAX_REFS, overflow_at[t],
+                 overflow_x[t]);
+            return nullptr;
+        }
+    // Phase 2, in band order: a run continues the span above it when interval and owners are the same (spans of the
+    // previous band sorted by xa, the band's runs too: a two-pointer walk), else it opens a new span.
     struct Open {
         int xa, xb;
         int64_t index;   // into spans
         Owners own;
     };
     std::vector<Open> open, open_next;
-
-    std::vector<int> xs, owner_of, skip;
-    for (size_t b = 0; b + 1 < ys.size(); ++b) {
-        const int ya = ys[b], yb = ys[b + 1];
-        while (next < by_y0.size() && cl[by_y0[next]].y0 <= ya) {
-            active.insert(std::upper_bound(active.begin(), active.end(), by_y0[next]), by_y0[next]);
-            ++next;
-        }
-        active.erase(std::remove_if(active.begin(), active.end(), [&](int i) { return cl[i].y1 <= ya; }), active.end());
-
-        xs.clear();
-        xs.push_back(0);
-        xs.push_back(canvas_w);
-        for (int i : active) {
-            xs.push_back(cl[i].x0);
-            xs.push_back(cl[i].x1);
-        }
-        std::sort(xs.begin(), xs.end());
-        xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
-
-        open_next.clear();
-        size_t op = 0;   // pointer into `open`
-        int cur_xa = 0, cur_xb = 0;
-        Owners cur;
-        bool have = false;
-        auto flush = [&]() {
-            if (!have) return;
-            while (op < open.size() && open[op].xa < cur_xa) ++op;
-            int64_t index;
-            if (op < open.size() && open[op].xa == cur_xa && open[op].xb == cur_xb && open[op].own == cur) {
-                index = open[op].index;
-                spans[index].h += yb - ya;
-            } else {
-                Span sp{};
-                sp.dst_y = ya;
-                sp.dst_x = cur_xa;
-                sp.h = yb - ya;
-                sp.w = cur_xb - cur_xa;
-                sp.nref = cur.n;
-                sp.ref0 = (int)refs.size();
-                for (int k = 0; k < cur.n; ++k) {
-                    const Clipped &c = cl[cur.v[k]];
-                    refs.push_back({c.tile, c.src_y + (ya - c.y0), c.src_x + (cur_xa - c.x0), 0});
-                }
-                index = (int64_t)spans.size();
-                spans.push_back(sp);
-            }
-            open_next.push_back({cur_xa, cur_xb, index, cur});
-            if (cur.n) covered += (int64_t)(yb - ya) * (cur_xb - cur_xa);
-            max_refs = std::max(max_refs, cur.n);
-            have = false;
-        };
-        const size_t m = xs.size() - 1;   // elementary x intervals of this band
-        if (mode == SQ_FUSE_OVERWRITE) {
-            // last writer wins: paint the intervals from the last active rect to the first, each interval
-            // once (skip pointers jump over what is already painted)
-            owner_of.assign(m, -1);
-            skip.resize(m + 1);
-            for (size_t k = 0; k <= m; ++k) skip[k] = (int)k;
-            auto find = [&](int k) {
-                while (skip[k] != k) k = skip[k] = skip[skip[k]];
-                return k;
-            };
-            for (size_t a = active.size(); a-- > 0;) {
-                const Clipped &c = cl[active[a]];
-                const int lo = (int)(std::lower_bound(xs.begin(), xs.end(), c.x0) - xs.begin());
-                const int hi = (int)(std::lower_bound(xs.begin(), xs.end(), c.x1) - xs.begin());
-                for (int k = find(lo); k < hi; k = find(k + 1)) {
-                    owner_of[k] = active[a];
-                    skip[k] = k + 1;
-                }
-            }
-        }
-        for (size_t k = 0; k < m; ++k) {
-            const int xa = xs[k], xb = xs[k + 1];
-            Owners own;
-            if (mode == SQ_FUSE_OVERWRITE) {
-                if (owner_of[k] >= 0) own.v[own.n++] = owner_of[k];
-            } else {
-                for (int i : active)
-                    if (cl[i].x0 <= xa && cl[i].x1 >= xb) {
-                        if (own.n == MAX_REFS) {
-                            fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: more than %d tiles overlap at canvas (%d,%d)",
-                                 MAX_REFS, ya, xa);
-                            return nullptr;
-                        }
-                        own.v[own.n++] = i;
+    for (int t = 0; t < sweep_threads; ++t) {
+        const std::vector<Run> &rs = runs_of[t];
+        size_t at = 0;
+        for (size_t k = 0; k < run_end[t].size(); ++k) {
+            const size_t b = first_band[t] + k;
+            const int ya = ys[b], yb = ys[b + 1];
+            open_next.clear();
+            size_t op = 0;   // pointer into `open`
+            for (; at < run_end[t][k]; ++at) {
+                const Run &cur = rs[at];
+                while (op < open.size() && open[op].xa < cur.xa) ++op;
+                int64_t index;
+                if (op < open.size() && open[op].xa == cur.xa && open[op].xb == cur.xb && open[op].own == cur.own) {
+                    index = open[op].index;
+                    spans[index].h += yb - ya;
+                } else {
+                    Span sp{};
+                    sp.dst_y = ya;
+                    sp.dst_x = cur.xa;
+                    sp.h = yb - ya;
+                    sp.w = cur.xb - cur.xa;
+                    sp.nref = cur.own.n;
+                    sp.ref0 = (int)refs.size();
+                    for (int q = 0; q < cur.own.n; ++q) {
+                        const Clipped &c = cl[cur.own.v[q]];
+                        refs.push_back({c.tile, c.src_y + (ya - c.y0), c.src_x + (cur.xa - c.x0), 0});
                     }
+                    index = (int64_t)spans.size();
+                    spans.push_back(sp);
+                }
+                open_next.push_back({cur.xa, cur.xb, index, cur.own});
+                if (cur.own.n) covered += (int64_t)(yb - ya) * (cur.xb - cur.xa);
+                max_refs = std::max(max_refs, cur.own.n);
             }
-            if (have && cur == own && cur_xb == xa) {
-                cur_xb = xb;
-            } else {
-                flush();
-                cur_xa = xa;
-                cur_xb = xb;
-                cur = own;
-                have = true;
-            }
+            open.swap(open_next);
         }
-        flush();
-        open.swap(open_next);
     }
 
     const auto t_sweep = std::chrono::steady_clock::now();
@@ -404,21 +444,26 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         }
     });
     const int64_t n_items = (int64_t)items.size();
+    const auto t_gen = std::chrono::steady_clock::now();
 
     // seam owners: item J takes the seam on its left when the item I that ends where J begins covers the same rows
     // and both are at least a line wide (tile or zero fill, either side)
+    auto t_band = t_gen, t_sort = t_gen;
     seams.clear();
     if (mode == SQ_FUSE_OVERWRITE) {
         seams.assign(items.size(), Seam{-1, 0, 0, 0});
         const int nb = canvas_h / BLOCK_ROWS + 1;
         std::vector<int32_t> first(nb + 1, 0);
         by_band.resize(items.size());
+        // (a counting sort by one thread: splitting it over the planner's threads was measured on the GPU box and did not
+        // pay -- two more fork / joins for 0.5 ms of work)
         for (const Item &it : items) ++first[it.dst_y / BLOCK_ROWS + 1];
         for (int k = 0; k < nb; ++k) first[k + 1] += first[k];
         {
             std::vector<int32_t> at(first.begin(), first.end() - 1);
             for (size_t i = 0; i < items.size(); ++i) by_band[at[items[i].dst_y / BLOCK_ROWS]++] = (int32_t)i;
         }
+        t_band = std::chrono::steady_clock::now();
         // inside a band: by (first row, END column), so that the item ending where J begins is a binary search away
         // (a 100 x 100 grid has 100+ items per band and millions of items)
         auto end_key = [&](int32_t i) { return ((int64_t)items[i].dst_y << 32) | (uint32_t)(items[i].dst_x + (items[i].hw & 0xFFFF)); };
@@ -427,6 +472,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 std::sort(by_band.begin() + first[k], by_band.begin() + first[k + 1],
                           [&](int32_t a, int32_t b) { return end_key(a) < end_key(b); });
         });
+        t_sort = std::chrono::steady_clock::now();
         // J's record is written by the thread that owns j; the LEAVE_TAIL bit of its left neighbour I belongs to another
         // item's record (which its own thread may be flagging HAS_LEFT at this moment): both go in with atomic ORs
         parallel_ranges(nthreads, items.size(), [&](int, size_t j_lo, size_t j_hi) {
@@ -563,11 +609,12 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 #ifdef SQ_EXPERIMENTS
     if (getenv("SQ_PLAN_TIMING")) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[plan] sweep %.3f ms, items + seams %.3f ms, emit %.3f ms (%zu spans, %lld items, %d threads)\n",
-                ms(t_begin, t_sweep), ms(t_sweep, t_items), ms(t_items, t_order), n_spans_dbg, (long long)n_items, nthreads);
+        fprintf(stderr, "[plan] sweep %.3f ms, items %.3f, seam bands %.3f, seam sort %.3f, seam lookup + counts %.3f, emit %.3f ms (%zu spans, %lld items, %d threads)\n",
+                ms(t_begin, t_sweep), ms(t_sweep, t_gen), ms(t_gen, t_band), ms(t_band, t_sort), ms(t_sort, t_items), ms(t_items, t_order), n_spans_dbg,
+                (long long)n_items, nthreads);
     }
 #else
-    (void)t_begin; (void)t_sweep; (void)t_items; (void)t_order; (void)n_spans_dbg;
+    (void)t_begin; (void)t_sweep; (void)t_items; (void)t_order; (void)n_spans_dbg; (void)t_gen; (void)t_band; (void)t_sort;
 #endif
     return plan;
 }
