@@ -283,3 +283,33 @@ def test_bench_launcher_argv(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 3 and calls['cmd'][-4:] == ['--gpus', '2', '--steps', '1']
+
+
+def test_bench_arena_layout_views_do_not_alias():
+    """bench.alloc_planes('arena'): canvas slots and tile stacks interleaved in ONE allocation -- both are plain views (a
+    canvas at a plane stride that is a multiple of 128 bytes, dense tile stacks reachable through the pointer table) and
+    no canvas voxel shares a byte with a tile."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_test2', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, g, hc, wc = 3, 1, 101, 203
+    tiles, canvas = bench.alloc_planes(n, g, hc, wc, 'cpu', 'arena')
+    assert tuple(tiles.shape) == (n, 1, bench.TILE, bench.TILE) and tuple(canvas.shape) == (n, hc, wc)
+    assert canvas.stride(0) == tiles.stride(0) and (canvas.stride(0) * 2) % 128 == 0 and canvas.stride(1) == wc
+    assert all(tiles[p].is_contiguous() and canvas[p].is_contiguous() for p in range(n))
+    canvas.view(torch.int16).fill_(-1)                  # 0xFFFF everywhere in the canvas slots
+    tiles.view(torch.int16).fill_(7)
+    assert bool((canvas.view(torch.int16) == -1).all()) and bool((tiles.view(torch.int16) == 7).all())
+    # slot k's tile stack follows slot k's canvas, slot k + 1's canvas follows that
+    for k in range(n):
+        assert tiles[k].data_ptr() - canvas[k].data_ptr() == -(-(hc * wc * 2) // 4096) * 4096
+        if k:
+            assert canvas[k].data_ptr() - tiles[k - 1].data_ptr() == bench.TILE * bench.TILE * 2
+    order = torch.tensor([0], dtype=torch.int64)
+    table = bench.tile_pointer_table(tiles, [2, 0, 1], order, 'cpu')
+    assert table.tolist() == [tiles[2].data_ptr(), tiles[0].data_ptr(), tiles[1].data_ptr()]
+    # 'separate': two dense allocations, the same shapes
+    t2, c2 = bench.alloc_planes(n, g, hc, wc, 'cpu', 'separate')
+    assert t2.is_contiguous() and tuple(t2.shape) == tuple(tiles.shape) and tuple(c2.shape) == tuple(canvas.shape)
+    assert bench.tile_pointer_table(t2, range(n), order, 'cpu').tolist() == [t2[k].data_ptr() for k in range(n)]
