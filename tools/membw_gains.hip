@@ -342,6 +342,56 @@ __global__ __launch_bounds__(256) void k_rows_pp(const Geo P, const PlanePtrs D)
     }
 }
 
+// ---- the canvas' all-zero TAIL (the reference's oversize rows: 20 % of the voxels): a dense block of full-width rows ----
+// (a) cut like the plan cuts it today: items of 8 rows x 4096-byte pieces, wave w rows w and w + 4
+template <int Z>
+__global__ __launch_bounds__(256) void k_tail_items(const PlanePtrs D, size_t pitch, int rows, int pieces) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int band = blockIdx.x / pieces, piece = blockIdx.x % pieces;
+    const u32x4 v = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < 2; ++j) {
+        const int r = band * 8 + wave + 4 * j;
+        if (r >= rows) break;
+        const size_t row0 = (size_t)r * pitch;
+        const size_t seg0 = row0 + (size_t)piece * 4096, seg1 = min(row0 + pitch, seg0 + 4096);
+#pragma unroll
+        for (int z = 0; z < Z; ++z) {
+            char *d = D.d[z];
+            const size_t a0 = (seg0 + ((uintptr_t)(d + seg0) & 127 ? 128 - ((uintptr_t)(d + seg0) & 127) : 0));   // first line boundary
+            // head bytes before the first line boundary (multiples of 2 here: pitch even) -- one 16-byte store per lane where whole
+            for (size_t q = seg0 + lane * 16; q + 16 <= a0 && q + 16 <= seg1; q += 64 * 16) st_nt(d + q, v);
+            for (int k = 0; k < 5; ++k) {
+                const size_t q = a0 + ((size_t)lane + 64 * k) * 16;
+                if (q + 16 <= seg1) st_nt(d + q, v);
+            }
+        }
+    }
+}
+// (b) one full row per workgroup, the four waves a contiguous quarter each (line-aligned split)
+template <int Z>
+__global__ __launch_bounds__(256) void k_tail_rows(const PlanePtrs D, size_t pitch, int rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t row0 = (size_t)blockIdx.x * pitch;
+    const u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int z = 0; z < Z; ++z) {
+        char *d = D.d[z];
+        const size_t first = (row0 + 15) / 16 * 16, last = (row0 + pitch) / 16 * 16;     // whole 16-byte vectors of the row
+        const size_t nvec = (last - first) / 16, per = (nvec + 3) / 4;
+        const size_t v0 = wave * per, v1 = min(nvec, v0 + per);
+        for (size_t i = v0 + lane; i < v1; i += 64) st_nt(d + first + i * 16, v);
+    }
+}
+// (c) the block as what it is: one contiguous run, 4 KiB per workgroup
+template <int Z>
+__global__ __launch_bounds__(256) void k_tail_linear(const PlanePtrs D, size_t bytes) {
+    const size_t q = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    const u32x4 v = {0u, 0u, 0u, 0u};
+    if (q + 16 <= bytes)
+#pragma unroll
+        for (int z = 0; z < Z; ++z) st_nt(D.d[z] + q, v);
+}
+
 __global__ void k_compare(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *bad) {
     unsigned long long mine = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += a[i] != b[i];
@@ -442,6 +492,27 @@ int main(int argc, char **argv) {
         if (h) printf("!! %s: %s\n", what, buf);
         return buf;
     };
+    if (argc > 5 && atoi(argv[5]) == 400) {
+        // THE ZERO TAIL: 5 planes 16 GiB apart in one allocation (the arena's spacing), each with a dense tail of 15 128
+        // rows x 116 068 bytes (the headline grid's); the three ways of writing it
+        const size_t pitch = 116068, spacing = (size_t)16 << 30;
+        const int rows = 15128;
+        const size_t bytes = pitch * rows;
+        char *big;
+        CK(hipMalloc(&big, 4 * spacing + bytes + 4096));
+        PlanePtrs D;
+        for (int z = 0; z < Z; ++z) D.d[z] = big + z * spacing;
+        const int pieces = (int)((pitch + 4095) / 4096);
+        for (int round = 0; round < 3; ++round) {
+            const double ma = time_ms([&] { hipLaunchKernelGGL((k_tail_items<Z>), dim3((unsigned)((rows + 7) / 8 * pieces)), dim3(256), 0, 0, D, pitch, rows, pieces); }, reps);
+            const double mb = time_ms([&] { hipLaunchKernelGGL((k_tail_rows<Z>), dim3((unsigned)rows), dim3(256), 0, 0, D, pitch, rows); }, reps);
+            const double mc = time_ms([&] { hipLaunchKernelGGL((k_tail_linear<Z>), dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, 0, D, bytes); }, reps);
+            printf("round %d: zero tail of %d planes x %.2f GB: 8-row x 4-KiB items %.3f | one full row per workgroup %.3f | linear 4-KiB chunks %.3f of 8 TB/s\n",
+                   round, Z, bytes / 1e9, Z * bytes / ma / 1e6 / 8000, Z * bytes / mb / 1e6 / 8000, Z * bytes / mc / 1e6 / 8000);
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (argc > 5 && atoi(argv[5]) == 300) {
         // ADDRESS AXIS: one 64 GiB allocation; "plane" k starts k * STEP bytes into it.  Row fill on the pair (ref, k): which
         // stretches of the allocation collide with the stretch at `ref`?
