@@ -45,7 +45,7 @@ __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
 //     mixed-radix Cooley-Tukey with radix 4 / 2 / 3 / 5 / 7 / 11 / 13 butterflies (lines_fft_mixed), like pocketfft --
 //     the reference's FFT -- does for such lengths;
 //   * any other length n (large prime factors: 2084 = 4 * 521, 3122 = 2 * 7 * 223, 1031): Bluestein's chirp-z form
-//     through a SMOOTH length M >= 2n - 1 (not the next power of two: 2084 -> 4200 instead of 8192 points), which is
+//     through a SMOOTH length M >= 2n - 1 (not the next power of two: 2084 -> 4320 instead of 8192 points), which is
 //     how pocketfft treats those too.
 // The longest line is what fits the 160 KB of LDS beside a few hundred bytes of reduction scratch: 9728 points, i.e.
 // any smooth crop side up to 9728 and any crop side at all up to 4860 (a 9568 x 6380 sensor gives 4784 and 3190).

@@ -216,7 +216,7 @@ typedef struct sq_register_args {
  *   - a power of two: radix-2 FFT;
  *   - any other length whose prime factors are all <= 13 (1500, 3000, 6000 ...): mixed-radix Cooley-Tukey (radix 4 / 2 / 3 /
  *     5 / 7 / 11 / 13), directly, up to 9728 points;
- *   - any other length n <= 4860: Bluestein's chirp-z form through a smooth length M >= 2n - 1 (2084 -> 4200 points);
+ *   - any other length n <= 4860: Bluestein's chirp-z form through a smooth length M >= 2n - 1 (2084 -> 4320 points);
  * float64 throughout -- the factorisations pocketfft (the reference's FFT, via scipy / numpy) uses for such lengths.
  * Anything else: SQ_ERR_UNSUPPORTED.  (Crops are about half a tile side long, stitcher.py:504-506 / :517-519: this
  * covers every sensor up to 9720 pixels a side -- a 9568 x 6380 one gives 4784 and 3190 -- and smooth sides up to 19440.)
