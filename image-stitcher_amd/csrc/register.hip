@@ -34,7 +34,26 @@ namespace {
 struct cplx {
     double re, im;
 };
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// complex product with one rounding fewer per component (2 multiplies + 2 fused multiply-adds instead of 4 + 2: the
+// transforms and the upsampled DFT are bound by VALU issue, and nothing here is compared bit for bit with another FFT)
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {fma(a.re, b.re, -(a.im * b.im)), fma(a.re, b.im, a.im * b.re)}; }
+// acc + a * b, four fused multiply-adds
+__device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx acc) {
+    return {fma(-a.im, b.im, fma(a.re, b.re, acc.re)), fma(a.im, b.re, fma(a.re, b.im, acc.im))};
+}
+// walks e = l * n + j in steps of nt without a division per element: (l, j) of the first element and of the step
+struct Walk {
+    int l, j, dl, dj, n;
+    __device__ __forceinline__ Walk(int first, int step, int n_) : l(first / n_), j(first % n_), dl(step / n_), dj(step % n_), n(n_) {}
+    __device__ __forceinline__ void next() {
+        l += dl;
+        j += dj;
+        if (j >= n) {
+            j -= n;
+            ++l;
+        }
+    }
+};
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
@@ -133,6 +152,7 @@ struct Layout {
     int64_t twm0, twm1, chirp0, chirp1, cspec0, cspec1;   // Bluestein tables per axis (unused for a smooth length)
     int64_t perm0, perm1;        // position of frequency k in a mixed-radix line (int32 per point; unused otherwise)
     int n0, n1, n1h, region, up;
+    int sp;          // row pitch of the half spectra in elements: n1h rounded up to whole 128-byte lines (8 complex doubles)
     int m0, m1;      // Bluestein FFT length per axis, 0 = the axis length is smooth (transformed directly)
     AxisPlan ax0, ax1;           // stages of the axis' transform (of length n, or of the Bluestein length m)
     int64_t per_pair_spec;
@@ -143,6 +163,7 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     L.n0 = n0;
     L.n1 = n1;
     L.n1h = n1 / 2 + 1;
+    L.sp = (L.n1h + 7) & ~7;
     L.up = up;
     L.region = (int)((up * 3 + 1) / 2);   // ceil(up * 1.5) for integer up (skimage :233)
     int64_t off = 0;
@@ -174,7 +195,8 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     off += (!L.m0 && L.ax0.nf) ? align16((int64_t)n0 * 4) : 0;
     L.perm1 = off;
     off += (!L.m1 && L.ax1.nf) ? align16((int64_t)n1 * 4) : 0;
-    L.per_pair_spec = (int64_t)n0 * L.n1h * 16;
+    L.per_pair_spec = (int64_t)n0 * L.sp * 16;
+    off = (off + 127) & ~int64_t(127);      // rows of the spectra start on 128-byte lines (of a 128-byte-aligned workspace)
     L.spectra = off;
     off += 2 * L.per_pair_spec * n_pairs;
     L.amps = off;
@@ -203,6 +225,7 @@ struct RegParams {
     Layout L;
     int32_t n_pairs, normalization, tc, rl_fwd, rl_inv;   // tc: columns per block (K2); rl_*: lines per block (K1, K3)
     int32_t n_tiles, tile_h, tile_w;
+    int32_t share;         // K2: blocks that share 128-byte lines of the spectra (see columns_kernel)
 };
 
 // everything a line transform along one axis needs (see lines_fft)
@@ -296,7 +319,7 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
         const int half = 1 << (s - 1);
         const int ts1 = n >> s, ts2 = n >> (s + 1);
         for (int e = tid; e < nlines * quads; e += nt) {
-            const int l = e / quads, q = e - l * quads;
+            const int l = e >> (logn - 2), q = e & (quads - 1);
             const int k = q & (half - 1);
             cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
             const cplx w1 = twiddle<INV>(tw, k * ts1);
@@ -668,7 +691,7 @@ template <typename T, bool GEN>
 __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n1 = L.n1, n1h = L.n1h, rl = P.rl_fwd;
+    const int n1 = L.n1, n1h = L.n1h, sp = L.sp, rl = P.rl_fwd;
     const Axis X = axis_of(P, 1);
     const int ld = X.ld;                           // line pitch: the Bluestein length when n1 needs one
     cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
@@ -676,10 +699,10 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
     const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
     const int tid = threadIdx.x, nt = blockDim.x;
-    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r0 * n1h;
-    cplx *B = A + (int64_t)L.n0 * n1h;
+    cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)r0 * sp;
+    cplx *B = A + (int64_t)L.n0 * sp;
     if (!pair_ok(P, pr)) {   // uniform per block
-        for (int e = tid; e < nrow * n1h; e += nt) A[e] = B[e] = {0.0, 0.0};
+        for (int e = tid; e < nrow * sp; e += nt) A[e] = B[e] = {0.0, 0.0};
         return;
     }
     const T *ref = P.tile_ptrs ? static_cast<const T *>(P.tile_ptrs[pr.ref_tile])
@@ -688,28 +711,31 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
                                : static_cast<const T *>(P.tile_base) + pr.mov_tile * P.tile_stride;
     const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
     const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
-    for (int e = tid; e < nrow * n1; e += nt) {
-        const int l = e / n1, j = e - l * n1;
+    Walk wi(tid, nt, n1);
+    for (int e = tid; e < nrow * n1; e += nt, wi.next()) {
+        const int l = wi.l, j = wi.j;
         const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
         const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
         x[(int64_t)l * ld + j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     }
     __syncthreads();
     lines_fft<false, false, GEN>(x, X, nrow, tid, nt);
-    for (int e = tid; e < nrow * n1h; e += nt) {
-        const int l = e / n1h, k = e - l * n1h;
+    Walk wo(tid, nt, n1h);
+    for (int e = tid; e < nrow * n1h; e += nt, wo.next()) {
+        const int l = wo.l, k = wo.j;
         const cplx *xl = x + (int64_t)l * ld;
         const cplx zk = xl[pos_of(X, k)], zc = cconj(xl[pos_of(X, k ? n1 - k : 0)]);
         // A = (Z[k] + conj Z[-k]) / 2 ;  B = (Z[k] - conj Z[-k]) / (2i)
-        A[e] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
+        const int64_t at = (int64_t)l * sp + k;
+        A[at] = {0.5 * (zk.re + zc.re), 0.5 * (zk.im + zc.im)};
         const cplx d = {zk.re - zc.re, zk.im - zc.im};
-        B[e] = {0.5 * d.im, -0.5 * d.re};
+        B[at] = {0.5 * d.im, -0.5 * d.re};
         // A constant tile normalises to zeros (0/0 -> NaN -> 0, stitcher.py:613-617) and its spectrum is exactly
         // zero in the reference; packed with the other image, the separation above would leave that image's
         // rounding noise (1e-16 of its magnitude) in it, and with nothing else in the cross-power spectrum the
         // noise would pick the peak.  (Golden case reg_blank_centre: the reference lands on index 0.)
-        if (rrange == 0.0) A[e] = {0.0, 0.0};
-        if (mrange == 0.0) B[e] = {0.0, 0.0};
+        if (rrange == 0.0) A[at] = {0.0, 0.0};
+        if (mrange == 0.0) B[at] = {0.0, 0.0};
     }
 }
 
@@ -723,19 +749,38 @@ template <bool GEN>
 __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n0 = L.n0, n1h = L.n1h, tc = P.tc;
+    const int n0 = L.n0, n1h = L.n1h, sp = L.sp, tc = P.tc;
     cplx *f = reinterpret_cast<cplx *>(smem);   // [tc][n0]
     cplx *g = f + (int64_t)tc * n0;             // [tc][n0]
     __shared__ double red[2][SQ_COL_THREADS / 64];
-    const int pair = blockIdx.y, c0 = blockIdx.x * tc;
+    // Which columns: a block's pieces of a spectrum row are tc * 16 bytes, so 8 / tc neighbouring blocks read and write
+    // the same 128-byte lines.  Workgroups go to the 8 XCDs (each with its own L2) round-robin by their linear index:
+    // the blocks that share lines are made the ones an XCD receives back to back -- linear index l, l + 8, ... -- so
+    // that the second to last find the line in that L2 instead of each fetching it from HBM again (FETCH_SIZE of this
+    // kernel was 2.7 x the spectra with neighbours on different XCDs).  P.share = 8 / tc when that is 2, 4 or 8, else 1;
+    // gridDim.x is a multiple of it (blocks past the last column leave at once).
+    int pair = blockIdx.y, cb = blockIdx.x;
+    if (P.share > 1) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, span = 8 * P.share, total = gridDim.x * gridDim.y;
+        const int base = lin / span * span;
+        if (base + span <= total) {
+            const int in = lin - base;
+            const int v = base + (in & 7) * P.share + (in >> 3);
+            pair = v / (int)gridDim.x;
+            cb = v - pair * (int)gridDim.x;
+        }
+    }
+    const int c0 = cb * tc;
+    if (c0 >= n1h) return;
     const int ncol = min(tc, n1h - c0);
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
-    cplx *B = A + (int64_t)n0 * n1h;
-    for (int i = tid; i < n0 * ncol; i += nt) {
-        const int r = i / ncol, c = i - r * ncol;
-        f[(int64_t)c * n0 + r] = A[(int64_t)r * n1h + c0 + c];
-        g[(int64_t)c * n0 + r] = B[(int64_t)r * n1h + c0 + c];
+    cplx *B = A + (int64_t)n0 * sp;
+    Walk wl(tid, nt, ncol);
+    for (int i = tid; i < n0 * ncol; i += nt, wl.next()) {
+        const int r = wl.l, c = wl.j;
+        f[(int64_t)c * n0 + r] = A[(int64_t)r * sp + c0 + c];
+        g[(int64_t)c * n0 + r] = B[(int64_t)r * sp + c0 + c];
     }
     __syncthreads();
     const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
@@ -784,15 +829,17 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
         __syncthreads();
     }
     // the product is what the upsampled DFT reads (skimage :239): keep it in B
-    for (int i = tid; i < n0 * ncol; i += nt) {
-        const int r = i / ncol, c = i - r * ncol;
-        B[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + pos_of(X, r)];
+    Walk wb(tid, nt, ncol);
+    for (int i = tid; i < n0 * ncol; i += nt, wb.next()) {
+        const int r = wb.l, c = wb.j;
+        B[(int64_t)r * sp + c0 + c] = f[(int64_t)c * n0 + pos_of(X, r)];
     }
     __syncthreads();
     lines_fft<true, true, GEN>(f, X, ncol, tid, nt);
-    for (int i = tid; i < n0 * ncol; i += nt) {
-        const int r = i / ncol, c = i - r * ncol;
-        A[(int64_t)r * n1h + c0 + c] = f[(int64_t)c * n0 + r];
+    Walk wa(tid, nt, ncol);
+    for (int i = tid; i < n0 * ncol; i += nt, wa.next()) {
+        const int r = wa.l, c = wa.j;
+        A[(int64_t)r * sp + c0 + c] = f[(int64_t)c * n0 + r];
     }
 }
 
@@ -804,27 +851,27 @@ template <bool GEN>
 __global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n0 = L.n0, n1h = L.n1h;
+    const int n0 = L.n0, n1h = L.n1h, sp = L.sp;
     cplx *x = reinterpret_cast<cplx *>(smem);   // [ld]
     __shared__ double red[2][1024 / 64];
     const int pair = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
-    cplx *B = A + (int64_t)n0 * n1h;
+    cplx *B = A + (int64_t)n0 * sp;
     const Axis X = axis_of(P, 0);
-    for (int r = tid; r < n0; r += nt) x[r] = A[(int64_t)r * n1h];
+    for (int r = tid; r < n0; r += nt) x[r] = A[(int64_t)r * sp];
     __syncthreads();
     lines_fft<false, false, GEN>(x, X, 1, tid, nt);
-    for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[pos_of(X, r)];   // F, natural order; re-read below by this very thread
+    for (int r = tid; r < n0; r += nt) A[(int64_t)r * sp] = x[pos_of(X, r)];   // F, natural order; re-read below by this very thread
     __syncthreads();
-    for (int r = tid; r < n0; r += nt) x[r] = B[(int64_t)r * n1h];
+    for (int r = tid; r < n0; r += nt) x[r] = B[(int64_t)r * sp];
     __syncthreads();
     lines_fft<false, false, GEN>(x, X, 1, tid, nt);
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double sf = 0.0, sg = 0.0;
     for (int r = tid; r < n0; r += nt) {
         const int at = pos_of(X, r);
-        const cplx F = A[(int64_t)r * n1h], G = x[at];
+        const cplx F = A[(int64_t)r * sp], G = x[at];
         sf += F.re * F.re + F.im * F.im;
         sg += G.re * G.re + G.im * G.im;
         cplx pr = cmul(F, cconj(G));                              // skimage :211
@@ -833,7 +880,7 @@ __global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
             pr.re *= scl;
             pr.im *= scl;
         }
-        B[(int64_t)r * n1h] = pr;              // the product is what the upsampled DFT reads (skimage :239)
+        B[(int64_t)r * sp] = pr;              // the product is what the upsampled DFT reads (skimage :239)
         x[at] = pr;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -856,7 +903,7 @@ __global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
         amps[1] = b;
     }
     lines_fft<true, true, GEN>(x, X, 1, tid, nt);
-    for (int r = tid; r < n0; r += nt) A[(int64_t)r * n1h] = x[r];
+    for (int r = tid; r < n0; r += nt) A[(int64_t)r * sp] = x[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -868,11 +915,16 @@ struct Best {
     int nan;
 };
 __device__ __forceinline__ Best better(Best a, Best b) {
-    // numpy argmax: NaN is the maximum; first occurrence wins
-    if (a.nan != b.nan) return a.nan ? a : b;
-    if (a.nan) return a.idx < b.idx ? a : b;
-    if (a.v != b.v) return a.v > b.v ? a : b;
-    return a.idx < b.idx ? a : b;
+    // numpy argmax: NaN is the maximum; first occurrence wins.  One predicate and three selects: returning one of
+    // the two structs by an if / else chain made the compiler keep both in scratch memory and load the winner through a
+    // selected address (69 scratch instructions in the row kernel's scan).
+    const bool first = a.idx < b.idx;
+    const bool take_a = a.nan != b.nan ? a.nan != 0 : (a.nan || a.v == b.v ? first : a.v > b.v);
+    Best r;
+    r.v = take_a ? a.v : b.v;
+    r.idx = take_a ? a.idx : b.idx;
+    r.nan = take_a ? a.nan : b.nan;
+    return r;
 }
 __device__ __forceinline__ Best make_best(double v, long long idx) { return {v, idx, v != v ? 1 : 0}; }
 __device__ Best block_best(Best b, int tid, int nt) {
@@ -916,7 +968,7 @@ template <bool GEN>
 __global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, rl = P.rl_inv;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, sp = L.sp, rl = P.rl_inv;
     const int nrp = (n0 + 1) / 2;
     const Axis X = axis_of(P, 1);
     const int ld = X.ld;
@@ -925,11 +977,12 @@ __global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
     const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
     const cplx *Q = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
-    for (int e = tid; e < nline * n1; e += nt) {
-        const int l = e / n1, k = e - l * n1;
+    Walk wq(tid, nt, n1);
+    for (int e = tid; e < nline * n1; e += nt, wq.next()) {
+        const int l = wq.l, k = wq.j;
         const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);   // odd n0: the last line repeats its row
         const bool two = (y0 + 1) < n0;
-        const cplx *q0 = Q + (int64_t)y0 * n1h, *q1 = Q + (int64_t)y1 * n1h;
+        const cplx *q0 = Q + (int64_t)y0 * sp, *q1 = Q + (int64_t)y1 * sp;
         // Hermitian extension of the half spectrum of a real row: X[n1-k] = conj X[k]
         cplx a, b;
         if (k < n1h) {
@@ -1028,75 +1081,92 @@ __device__ __forceinline__ int posmod(long long a, int m) {
 // k0 -- so it is built once per block and reused by every row of the block's tile instead of being
 // looked up per element (the first version did that, with a 64-bit modulo each, and reduced across
 // the block once per output: 42 % of an all-pairs batch).
-// Block = 128 (or 16) rows k0 of one pair, 256 threads, thread tile = 2 rows x 4 outputs (or 1 x 1), the k1 range in
-// chunks of 16 (64 in the small variant) staged through LDS (row pitch padded by one element: the 16 rows a wave reads at one
-// k1 fall into distinct banks).  Every output is summed over k1 in ascending order by one thread:
-// no cross-thread reduction, nothing depends on scheduling.
-// Thread tile TR rows x TB outputs: 2 x 4 (128 rows per block) for batches, 1 x 1 (16 rows per block)
-// when there are too few pairs to fill the chip with 128-row blocks (the bench's two centre pairs).
+// Only the half spectrum k1 < n1h is stored; the other half is conj P[-k0][n1 - k1].  A block therefore takes ROWS
+// rows 0 < k0 < n0 / 2 TOGETHER WITH their mirror rows -k0 (the two rows that are their own mirrors, 0 and -- for an
+// even n0 -- n0 / 2, share the first slot): with both tiles in LDS,
+//     D1[ k0][b] = sum_{k1 < n1h} P[k0][k1] W[k1][b] + conj(P[-k0][k1]) W[n1 - k1][b]
+//     D1[-k0][b] = sum_{k1 < n1h} P[-k0][k1] W[k1][b] + conj(P[k0][k1]) W[n1 - k1][b]
+// (second terms for 1 <= k1 <= n1 - n1h only), so every element of the product is read from HBM once -- the version
+// that took rows one tile at a time read it twice (FETCH_SIZE 6.2 GB per 992-pair batch for a 2.1 GB product, at
+// 3.9 TB/s: the kernel is bound by that read).
+// Block = 64 (or 16) row pairs of one pair, 256 threads, thread tile = one row and its mirror x 4 outputs (or x 1),
+// the k1 range in chunks of 16 (32 in the small variant) staged through LDS (row pitch padded by one element: the 16
+// rows a wave reads at one k1 fall into distinct banks).  Every output is summed over k1 in ascending order by one
+// thread: no cross-thread reduction, nothing depends on scheduling.
+// TB = 4 (64 row pairs per block) for batches, 1 (16 row pairs per block) when there are too few pairs to fill the
+// chip with the larger blocks (the bench's two centre pairs).
 constexpr int UR_B = 16;
-template <int TR, int TB, int UR_KC>
+template <int TB, int UR_KC>
 __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
-    constexpr int ROWS = 256 / (UR_B / TB) * TR;
+    constexpr int ROWS = 256 / (UR_B / TB);
     const Layout &L = P.L;
-    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, R = L.region, up = L.up;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, sp = L.sp, R = L.region, up = L.up;
     const int pair = blockIdx.y, row0 = blockIdx.x * ROWS;
     const int tid = threadIdx.x;
     const int *pk = reinterpret_cast<const int *>(P.ws + L.peak) + 4 * pair;
     // shifts = round(shifts*u)/u is the integer peak; offset = fix(R/2) - shift*u (skimage :232-238)
     const int off1 = R / 2 - pk[1] * up;
-    const cplx *Pm = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)n0 * n1h;
+    const cplx *Pm = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + (int64_t)n0 * sp;
     const cplx *E = reinterpret_cast<const cplx *>(P.ws + L.up1);
     const int M = n1 * up;
-    __shared__ cplx Pl[ROWS][UR_KC + 1];
-    __shared__ cplx Wl[UR_KC][UR_B];
-    const int rt = tid / (UR_B / TB), bt = tid % (UR_B / TB);   // rows TR*rt .., outputs TB*bt .. of the chunk
+    // slot k0 holds the rows (k0, n0 - k0); slot 0 the self-mirrored rows (0, n0 / 2) [even n0] or row 0 alone [odd n0]
+    const int n_slots = (n0 + 1) / 2, nyquist = (n0 & 1) ? -1 : n0 / 2;
+    const int n_mirror = n1 - n1h;           // k1 = 1 .. n_mirror have a mirror column n1 - k1 >= n1h
+    __shared__ cplx Pl[2][ROWS][UR_KC + 1];  // [0]: rows k0, [1]: rows -k0
+    __shared__ cplx Wl[2][UR_KC][UR_B];      // [0]: W[k1], [1]: W[n1 - k1] (zero where k1 has no mirror)
+    const int rt = tid / (UR_B / TB), bt = tid % (UR_B / TB);   // slot rt, outputs TB*bt .. of the chunk
+    const bool self = row0 + rt == 0;
     for (int b0 = 0; b0 < R; b0 += UR_B) {
-        cplx acc[TR][TB];
+        cplx acc[2][TB];
 #pragma unroll
-        for (int i = 0; i < TR; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TB; ++j) acc[i][j] = {0.0, 0.0};
-        for (int kc = 0; kc < n1; kc += UR_KC) {
-            // stage the spectrum tile: P[k0][k1] for k1 < n1h, conj P[-k0][n1 - k1] beyond (Hermitian half)
-            for (int e = tid; e < ROWS * UR_KC; e += 256) {
-                const int i = e / UR_KC, k = e - i * UR_KC;
+        for (int kc = 0; kc < n1h; kc += UR_KC) {
+            for (int e = tid; e < 2 * ROWS * UR_KC; e += 256) {
+                const int m = e / (ROWS * UR_KC), ik = e - m * (ROWS * UR_KC);
+                const int i = ik / UR_KC, k = ik - i * UR_KC;
                 const int k0 = row0 + i, k1 = kc + k;
                 cplx v = {0.0, 0.0};
-                if (k0 < n0 && k1 < n1)
-                    v = k1 < n1h ? Pm[(int64_t)k0 * n1h + k1] : cconj(Pm[(int64_t)((n0 - k0) % n0) * n1h + (n1 - k1)]);
-                Pl[i][k] = v;
+                const int row = m ? (k0 ? n0 - k0 : nyquist) : k0;
+                if (k0 < n_slots && row >= 0 && k1 < n1h) v = Pm[(int64_t)row * sp + k1];
+                Pl[m][i][k] = v;
             }
-            for (int e = tid; e < UR_KC * UR_B; e += 256) {   // and the phase tile
-                const int k = e / UR_B, b = e - k * UR_B;
+            for (int e = tid; e < 2 * UR_KC * UR_B; e += 256) {   // and the phase tiles
+                const int m = e / (UR_KC * UR_B), kb = e - m * (UR_KC * UR_B);
+                const int k = kb / UR_B, b = kb - k * UR_B;
                 const int k1 = kc + k;
                 cplx w = {0.0, 0.0};
-                if (k1 < n1 && b0 + b < R) w = E[posmod((long long)(b0 + b - off1) * signed_freq(k1, n1), M)];
-                Wl[k][b] = w;
+                const bool live = m ? (k1 >= 1 && k1 <= n_mirror) : k1 < n1h;
+                if (live && b0 + b < R) w = E[posmod((long long)(b0 + b - off1) * signed_freq(m ? n1 - k1 : k1, n1), M)];
+                Wl[m][k][b] = w;
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < UR_KC; ++k) {
-                cplx p[TR];
-#pragma unroll
-                for (int i = 0; i < TR; ++i) p[i] = Pl[TR * rt + i][k];
+                const cplx p = Pl[0][rt][k], q = Pl[1][rt][k];
+                // the conjugated term comes from the mirror row: the other row of the slot, or the row itself in slot 0
+                const cplx pm = cconj(self ? p : q), qm = cconj(self ? q : p);
 #pragma unroll
                 for (int j = 0; j < TB; ++j) {
-                    const cplx w = Wl[k][TB * bt + j];
-#pragma unroll
-                    for (int i = 0; i < TR; ++i) acc[i][j] = cadd(acc[i][j], cmul(p[i], w));
+                    const cplx w = Wl[0][k][TB * bt + j], wm = Wl[1][k][TB * bt + j];
+                    acc[0][j] = cfma(pm, wm, cfma(p, w, acc[0][j]));
+                    acc[1][j] = cfma(qm, wm, cfma(q, w, acc[1][j]));
                 }
             }
             __syncthreads();
         }
+        const int k0 = row0 + rt;
+        if (k0 < n_slots) {
+            const int km = k0 ? n0 - k0 : nyquist;
 #pragma unroll
-        for (int i = 0; i < TR; ++i) {
-            const int k0 = row0 + TR * rt + i;
-            if (k0 >= n0) continue;
-            cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + k0) * R;
+            for (int i = 0; i < 2; ++i) {
+                if (i && km < 0) continue;         // odd n0: row 0 is alone in its slot
+                cplx *D1 = reinterpret_cast<cplx *>(P.ws + L.d1) + ((int64_t)pair * n0 + (i ? km : k0)) * R;
 #pragma unroll
-            for (int j = 0; j < TB; ++j)
-                if (b0 + TB * bt + j < R) D1[b0 + TB * bt + j] = acc[i][j];
+                for (int j = 0; j < TB; ++j)
+                    if (b0 + TB * bt + j < R) D1[b0 + TB * bt + j] = acc[i][j];
+            }
         }
     }
 }
@@ -1302,9 +1372,27 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     P.n_tiles = a->n_tiles;
     P.tile_h = a->tile_h;
     P.tile_w = a->tile_w;
-    // columns per block (directly transformed axis 0): two [tc][n0] complex arrays in 144 KiB of LDS; a longer column,
-    // or one that needs a Bluestein line, goes one per block (columns_single_kernel)
-    const int tc = L.m0 ? 0 : (int)std::min<int64_t>(8, (144 * 1024) / (2 * (int64_t)L.n0 * 16));
+    // columns per block (directly transformed axis 0): two [tc][n0] complex arrays in LDS; a column too long for two to fit
+    // (n0 > 4608), or one that needs a Bluestein line, goes one per block (columns_single_kernel).  SMALL blocks: a block
+    // runs its phases one after the other (strided load, transforms, product, store, inverse, store), and only other
+    // blocks of the CU can fill the gaps -- 16 KiB of columns per block (2 x 256 or, for longer columns, a single one)
+    // with 256 threads measured 9.5 / 10.0 ms per 992-pair batch of 256- / 1024-point columns against 11.2 / 11.2 ms
+    // with 128 KiB / 512 threads (profiles/r03_exp_registration_shapes.log).  A power of two, so that 8 / tc blocks
+    // share the spectra's 128-byte lines (P.share).
+    int tc = 0;
+    if (!L.m0 && 2 * (int64_t)L.n0 * 16 <= 144 * 1024) {
+        tc = 1;
+        while (tc < 8 && 2 * (int64_t)(2 * tc) * L.n0 * 16 <= 16 * 1024) tc *= 2;
+        // ... but enough lines that a stage has a butterfly for every thread: n0 / r of them per line, r the largest radix
+        int rmax = 4;
+        for (int i = 0; i < L.ax0.nf; ++i) rmax = std::max(rmax, L.ax0.radix[i]);
+        while (tc < 8 && 2 * (int64_t)tc * (L.n0 / rmax) < 256 && 2 * (int64_t)(2 * tc) * L.n0 * 16 <= 144 * 1024) tc *= 2;
+    }
+    int col_threads = 2 * (int64_t)std::max(tc, 1) * L.n0 * 16 >= 64 * 1024 ? SQ_COL_THREADS : 256;   // a long column brings its own waves
+#ifdef SQ_EXPERIMENTS      // (the product library reads no environment variable)
+    if (const char *e = getenv("SQ_REG_TC")) tc = tc ? std::max(1, std::min(atoi(e), (int)((144 * 1024) / (2 * (int64_t)L.n0 * 16)))) : 0;
+    if (const char *e = getenv("SQ_REG_COL_THREADS")) col_threads = std::min(SQ_COL_THREADS, std::max(64, atoi(e)));
+#endif
     P.tc = tc;
     hipStream_t s = static_cast<hipStream_t>(stream_);
 
@@ -1325,8 +1413,12 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         while (rl > 1 && (int64_t)a->n_pairs * ((n_lines + rl - 1) / rl) < 512) rl >>= 1;
         return rl;
     };
-    const int rlf = lines_per_block((int)std::max<int64_t>(1, std::min<int64_t>(8, 16384 / line_bytes)), L.n0);
-    const int rli = lines_per_block(8, (L.n0 + 1) / 2);
+    int rlf = lines_per_block((int)std::max<int64_t>(1, std::min<int64_t>(8, 16384 / line_bytes)), L.n0);
+    int rli = lines_per_block((int)std::max<int64_t>(1, std::min<int64_t>(8, 32768 / line_bytes)), (L.n0 + 1) / 2);
+#ifdef SQ_EXPERIMENTS
+    if (const char *e = getenv("SQ_REG_RLF")) rlf = std::max(1, std::min<int>(atoi(e), (int)(160 * 1024 / line_bytes)));
+    if (const char *e = getenv("SQ_REG_RLI")) rli = std::max(1, std::min<int>(atoi(e), (int)(160 * 1024 / line_bytes)));
+#endif
     P.rl_fwd = rlf;
     P.rl_inv = rli;
     // one LONG line per block (a Bluestein line of thousands of points: up to 152 KB of LDS, so one or two blocks per CU):
@@ -1361,9 +1453,11 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         else SQ_LAUNCH(columns_single_kernel<false>, grid_col, ntc, lds_col);
     } else {
         const size_t lds_col = (size_t)2 * tc * L.n0 * 16;
-        const dim3 grid_col((L.n1h + tc - 1) / tc, a->n_pairs);
-        if (gen0) SQ_LAUNCH(columns_kernel<true>, grid_col, SQ_COL_THREADS, lds_col);
-        else SQ_LAUNCH(columns_kernel<false>, grid_col, SQ_COL_THREADS, lds_col);
+        const int share = (tc == 1 || tc == 2 || tc == 4) ? 8 / tc : 1;
+        P.share = share;
+        const dim3 grid_col(((L.n1h + tc - 1) / tc + share - 1) / share * share, a->n_pairs);
+        if (gen0) SQ_LAUNCH(columns_kernel<true>, grid_col, col_threads, lds_col);
+        else SQ_LAUNCH(columns_kernel<false>, grid_col, col_threads, lds_col);
     }
     const dim3 grid_inv(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs);
     if (gen1) SQ_LAUNCH(rows_inverse_kernel<true>, grid_inv, nti, lds_inv);
@@ -1371,10 +1465,11 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
 #undef SQ_LAUNCH
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     if (a->upsample_factor > 1) {
-        if ((int64_t)a->n_pairs * ((L.n0 + 127) / 128) >= 256)
-            hipLaunchKernelGGL((upsample_rows_kernel<2, 4, 16>), dim3((L.n0 + 127) / 128, a->n_pairs), dim3(256), 0, s, P);
+        const int row_pairs = (L.n0 + 1) / 2;    // slots of a row and its mirror (upsample_rows_kernel)
+        if ((int64_t)a->n_pairs * ((row_pairs + 63) / 64) >= 256)
+            hipLaunchKernelGGL((upsample_rows_kernel<4, 16>), dim3((row_pairs + 63) / 64, a->n_pairs), dim3(256), 0, s, P);
         else
-            hipLaunchKernelGGL((upsample_rows_kernel<1, 1, 64>), dim3((L.n0 + 15) / 16, a->n_pairs), dim3(256), 0, s, P);
+            hipLaunchKernelGGL((upsample_rows_kernel<1, 32>), dim3((row_pairs + 15) / 16, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_cols_kernel, dim3(L.region, a->n_pairs), dim3(256), 0, s, P);
         hipLaunchKernelGGL(upsample_peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);
     }
