@@ -1385,7 +1385,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         while (tc < 8 && 2 * (int64_t)(2 * tc) * L.n0 * 16 <= 16 * 1024) tc *= 2;
         // ... but enough lines that a stage has a butterfly for every thread: n0 / r of them per line, r the largest radix
         int rmax = 4;
-        for (int i = 0; i < L.ax0.nf; ++i) rmax = std::max(rmax, L.ax0.radix[i]);
+        for (int i = 0; i < L.ax0.nf; ++i) rmax = std::max<int>(rmax, L.ax0.radix[i]);
         while (tc < 8 && 2 * (int64_t)tc * (L.n0 / rmax) < 256 && 2 * (int64_t)(2 * tc) * L.n0 * 16 <= 144 * 1024) tc *= 2;
     }
     int col_threads = 2 * (int64_t)std::max(tc, 1) * L.n0 * 16 >= 64 * 1024 ? SQ_COL_THREADS : 256;   // a long column brings its own waves
