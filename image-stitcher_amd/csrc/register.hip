@@ -745,6 +745,27 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
 #ifndef SQ_COL_THREADS
 #define SQ_COL_THREADS 512
 #endif
+// Which columns a block of the column kernels takes.  A block's pieces of a spectrum row are tc * 16 bytes, so 8 / tc
+// neighbouring blocks read and write the same 128-byte lines.  Workgroups go to the 8 XCDs (each with its own L2)
+// round-robin by their linear index: the blocks that share lines are made the ones an XCD receives back to back --
+// linear index l, l + 8, ... -- so that the second to last find the line in that L2 instead of each fetching it from
+// HBM again (FETCH_SIZE of the column kernel was 2.7 x the spectra with neighbours on different XCDs).  share = 8 / tc
+// when that is 2, 4 or 8, else 1; gridDim.x is a multiple of it (blocks past the last column leave at once).
+__device__ __forceinline__ void column_block(int share, int &pair, int &cb) {
+    pair = blockIdx.y;
+    cb = blockIdx.x;
+    if (share > 1) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, span = 8 * share, total = gridDim.x * gridDim.y;
+        const int base = lin / span * span;
+        if (base + span <= total) {
+            const int in = lin - base;
+            const int v = base + (in & 7) * share + (in >> 3);
+            pair = v / (int)gridDim.x;
+            cb = v - pair * (int)gridDim.x;
+        }
+    }
+}
+
 template <bool GEN>
 __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -753,23 +774,8 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     cplx *f = reinterpret_cast<cplx *>(smem);   // [tc][n0]
     cplx *g = f + (int64_t)tc * n0;             // [tc][n0]
     __shared__ double red[2][SQ_COL_THREADS / 64];
-    // Which columns: a block's pieces of a spectrum row are tc * 16 bytes, so 8 / tc neighbouring blocks read and write
-    // the same 128-byte lines.  Workgroups go to the 8 XCDs (each with its own L2) round-robin by their linear index:
-    // the blocks that share lines are made the ones an XCD receives back to back -- linear index l, l + 8, ... -- so
-    // that the second to last find the line in that L2 instead of each fetching it from HBM again (FETCH_SIZE of this
-    // kernel was 2.7 x the spectra with neighbours on different XCDs).  P.share = 8 / tc when that is 2, 4 or 8, else 1;
-    // gridDim.x is a multiple of it (blocks past the last column leave at once).
-    int pair = blockIdx.y, cb = blockIdx.x;
-    if (P.share > 1) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, span = 8 * P.share, total = gridDim.x * gridDim.y;
-        const int base = lin / span * span;
-        if (base + span <= total) {
-            const int in = lin - base;
-            const int v = base + (in & 7) * P.share + (in >> 3);
-            pair = v / (int)gridDim.x;
-            cb = v - pair * (int)gridDim.x;
-        }
-    }
+    int pair, cb;
+    column_block(P.share, pair, cb);
     const int c0 = cb * tc;
     if (c0 >= n1h) return;
     const int ncol = min(tc, n1h - c0);
@@ -854,7 +860,9 @@ __global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
     const int n0 = L.n0, n1h = L.n1h, sp = L.sp;
     cplx *x = reinterpret_cast<cplx *>(smem);   // [ld]
     __shared__ double red[2][1024 / 64];
-    const int pair = blockIdx.y, c = blockIdx.x;
+    int pair, c;
+    column_block(P.share, pair, c);
+    if (c >= n1h) return;
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
     cplx *B = A + (int64_t)n0 * sp;
@@ -1447,7 +1455,8 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     }
     if (tc < 1) {
         const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
-        const dim3 grid_col(L.n1h, a->n_pairs);
+        P.share = 8;
+        const dim3 grid_col((L.n1h + 7) / 8 * 8, a->n_pairs);
         const int ntc = lds_col > 80 * 1024 ? 1024 : SQ_COL_THREADS;     // one block per CU: twice the waves
         if (gen0) SQ_LAUNCH(columns_single_kernel<true>, grid_col, ntc, lds_col);
         else SQ_LAUNCH(columns_single_kernel<false>, grid_col, ntc, lds_col);
