@@ -280,6 +280,10 @@ __device__ __forceinline__ bool pair_ok(const RegParams &P, const sq_pair &pr) {
 // the whole batch instead of one per line.
 // INV conjugates the twiddles (no 1/n scaling anywhere: only argmax and ratios are used).
 template <bool INV>
+__device__ __forceinline__ cplx rot90(cplx a) {   // a * (-i) forward, a * (+i) inverse
+    return INV ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
+}
+template <bool INV>
 __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
     cplx w = tw[idx];
     if (INV) w.im = -w.im;
@@ -317,13 +321,15 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
     const int quads = n >> 2;
     for (; s < logn; s += 2) {
         const int half = 1 << (s - 1);
-        const int ts1 = n >> s, ts2 = n >> (s + 1);
+        const int ts2 = n >> (s + 1);      // (ts1 = n >> s = 2 ts2 is the stride of the stage-s twiddle)
         for (int e = tid; e < nlines * quads; e += nt) {
             const int l = e >> (logn - 2), q = e & (quads - 1);
             const int k = q & (half - 1);
             cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
-            const cplx w1 = twiddle<INV>(tw, k * ts1);
-            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = twiddle<INV>(tw, (k + half) * ts2);
+            // one table read per butterfly: (k + half) ts2 = k ts2 + n / 4 and k ts1 = 2 k ts2, so w3 = -i w2 (+i inverse)
+            // and w1 = w2^2 -- the reads go through the L1 at 16 cycles per wave (three of them were 2.3e7 of the column
+            // kernel's 2.7e7 vector memory reads per 992-pair batch), the square is four VALU operations
+            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = rot90<INV>(w2), w1 = cmul(w2, w2);
             const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
             // stage s: (x0, x1) and (x2, x3), both with w1
             const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
@@ -349,10 +355,6 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
 //   DIT: a_q = x_q W_ms^(q k),  y_j = sum_q a_q W_r^(q j);      DIF: y_j = (sum_q x_q W_r^(q j)) W_ms^(j k).
 // Twiddles come from the full-circle table tw[t] = exp(-2 pi i t / N): W_ms^e = tw[e N / m_s] (e < m_s), W_r^e = tw[e N / r].
 // float64 throughout; INV conjugates every twiddle (no 1/N anywhere, like the power-of-two kernel).
-template <bool INV>
-__device__ __forceinline__ cplx rot90(cplx a) {   // a * (-i) forward, a * (+i) inverse
-    return INV ? cplx{-a.im, a.re} : cplx{a.im, -a.re};
-}
 template <int R, bool INV>
 __device__ __forceinline__ void small_dft(cplx (&a)[R], const cplx *__restrict__ tw, int N) {
     if constexpr (R == 2) {
