@@ -464,7 +464,8 @@ def run_region(ctx):
             'workload': job['config']['workload'], 'value': job['value'], 'unit': job['unit'], 'ms_per_step': job['ms_per_step'],
             'steps': 1, 'warmup': 1, 'scaling_note': 'the N = 1 point of the strong-scaling curve that bench.py --gpus N measures',
             'resident_batches': job['config']['resident_batches_per_gpu'], 'roofline_frac': job['roofline']['frac'],
-            'launch_ms': job['roofline']['launch_ms']}
+            'launch_ms': job['roofline']['launch_ms'], 'host_ms_per_job': job['host_ms_per_job_rank0'],
+            'registration': job['config']['registration']}
     return out
 
 
