@@ -140,4 +140,11 @@ struct sq_table {
 struct sq_fuse_plan {
     sq_table table;
     const sq::TableHeader &header() const { return *reinterpret_cast<const sq::TableHeader *>(table.data()); }
+    // A plan made by sq_fuse_plan_create_spans holds header + spans + refs (+ the spans' first item numbers) on the host;
+    // its items, seam records and their order are produced on the device by sq_fuse_plan_expand (plan_expand.hip).
+    bool spans_only = false;       // made by sq_fuse_plan_create_spans
+    bool expanded = false;         // sq_fuse_plan_expand has run: header().lane_items is valid, the device table complete
+    int64_t full_bytes = 0;        // size of the complete table (what the device buffer holds)
+    int64_t off_span_first = 0;    // host table: (n_spans + 1) int64 item numbers, after the refs
+    int64_t device_bytes() const { return spans_only ? full_bytes : (int64_t)table.size(); }
 };

@@ -1803,9 +1803,11 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
     if (!a || !a->plan || !a->table_dev || !a->canvas_dev)
         return fail(SQ_ERR_INVALID, "sq_fuse_planes: NULL plan/table/canvas");
     const TableHeader &h = a->plan->header();
-    if (a->table_bytes != (int64_t)a->plan->table.size())
-        return fail(SQ_ERR_INVALID, "sq_fuse_planes: table_bytes %lld != plan %zu", (long long)a->table_bytes,
-                    a->plan->table.size());
+    if (a->plan->spans_only && !a->plan->expanded)
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: the plan of sq_fuse_plan_create_spans has not been through sq_fuse_plan_expand");
+    if (a->table_bytes != a->plan->device_bytes())
+        return fail(SQ_ERR_INVALID, "sq_fuse_planes: table_bytes %lld != plan %lld", (long long)a->table_bytes,
+                    (long long)a->plan->device_bytes());
     if (a->mode != h.mode) return fail(SQ_ERR_INVALID, "sq_fuse_planes: mode %d but plan was built for %d", a->mode, h.mode);
     if (a->n_tiles != h.n_tiles || a->tile_h != h.tile_h || a->tile_w != h.tile_w || a->canvas_h != h.canvas_h ||
         a->canvas_w != h.canvas_w)

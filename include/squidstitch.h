@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 104 /* 0.1.3: sq_register_line_supported (mixed-radix / smooth-Bluestein lines up to 9728 points) */
+#define SQ_VERSION 105 /* 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -84,6 +84,19 @@ int sq_fuse_plan_export(const sq_fuse_plan *plan, void *host_buf, int64_t host_b
  * page-locked host memory when a device is present, so this is one DMA at link speed; prefer it to
  * sq_fuse_plan_export + a copy of your own. */
 int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *stream);
+/* The same plan with its work list produced ON THE DEVICE (overwrite mode; tiles up to 8176 rows): the host stops after
+ * the sweep into spans (1.2 of the 5 ms a 32 x 32 grid's plan takes) and uploads those -- ~100 KB instead of the 14.7 MB
+ * table; sq_fuse_plan_expand cuts them into items, finds the seam owners and orders the list with four kernels into the
+ * caller's table buffer (>= sq_fuse_plan_table_bytes) using a scratch buffer (>= sq_fuse_plan_expand_scratch_bytes, free
+ * again on return), and waits for them.  The table is sq_fuse_plan_create's byte for byte.  Such a plan has no host copy
+ * of its items: sq_fuse_plan_export / _upload refuse it, and sq_fuse_planes refuses it until it has been expanded.
+ * This is the first thing a job does after registration (reference: stitch_region's tile loop, stitcher.py:652-681,
+ * starts from the shifts the same way). */
+sq_fuse_plan *sq_fuse_plan_create_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+                                        int32_t canvas_h, int32_t canvas_w, int32_t mode);
+int64_t sq_fuse_plan_expand_scratch_bytes(const sq_fuse_plan *plan);
+int sq_fuse_plan_expand(sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *scratch_dev, int64_t scratch_bytes,
+                        void *stream);
 /* Introspection (tests, DESIGN.md numbers): n_spans, n_items, covered voxels, max tiles/span. */
 int sq_fuse_plan_stats(const sq_fuse_plan *plan, int64_t *n_spans, int64_t *n_items, int64_t *covered_voxels,
                        int32_t *max_refs);

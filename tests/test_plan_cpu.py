@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sq_version() == 104
+    assert L.sq_version() == 105
 
 
 def test_struct_layouts_match_header():
@@ -267,3 +267,25 @@ def test_register_line_lengths_supported_without_a_device():
         registration.check_crop_lengths(9722, 2048, 256, 256)
     assert L.sq_register_workspace_bytes(4, 6000, 300, 10) > 0
     assert L.sq_register_workspace_bytes(4, 4861, 300, 10) < 0 and b'not supported' in L.sq_last_error()
+
+
+def test_spans_only_plan_has_the_full_plans_sizes_without_a_device():
+    """sq_fuse_plan_create_spans (the host half of a plan whose work list is produced on the device, plan_expand.hip):
+    span / item counts, covered voxels and the size of the complete table equal sq_fuse_plan_create's; there is no host
+    copy of the items to export, and feather plans are refused."""
+    rng = np.random.default_rng(5)
+    for th, tw, ch, cw, n in ((37, 53, 150, 170, 20), (64, 2100, 300, 6000, 12), (16, 16, 16, 16, 0)):
+        rects = random_rects(rng, n, th, tw, ch, cw) if n else np.zeros((0, 6), dtype=int)
+        full = native.FusePlan(rects, th, tw, ch, cw)
+        part = native.FusePlan(rects, th, tw, ch, cw, expand_on_device=True)
+        assert part.expand_on_device
+        assert (part.n_spans, part.n_items, part.covered_voxels, part.max_refs, part.table_bytes) == \
+            (full.n_spans, full.n_items, full.covered_voxels, full.max_refs, full.table_bytes)
+        with pytest.raises(native.NativeError, match='no host copy'):
+            part.table
+        buf = np.empty(part.table_bytes, dtype=np.uint8)
+        assert native.lib().sq_fuse_plan_export(part.handle, buf.ctypes.data, buf.size) != 0
+        assert b'device' in native.lib().sq_last_error()
+    assert not native.FusePlan(np.array([(0, 0, 8, 8, 0, 0)]), 8, 8, 16, 16, native.SQ_FUSE_FEATHER, expand_on_device=True).expand_on_device
+    assert not native.lib().sq_fuse_plan_create_spans(None, 0, 8, 8, 16, 16, native.SQ_FUSE_FEATHER)
+    assert b'overwrite plans only' in native.lib().sq_last_error()
