@@ -298,17 +298,25 @@ def register_pair_subset(tiles, local_index, pairs, indices, height: int, width:
     if not len(indices):
         return out
     if minmax is None:
-        minmax = native.tile_minmax(tiles)
-    for kind, make, ov in ((PAIR_H, horizontal_pair, max_x_overlap), (PAIR_V, vertical_pair, max_y_overlap)):
-        slots = [k for k, i in enumerate(indices) if pairs[i][0] == kind]
-        if not slots:
+        minmax = native.tile_minmax(tiles)      # enqueued; the pair records below are made while it runs
+    code = _norm_code(normalization)
+    kinds = np.fromiter((pairs[i][0] for i in indices), dtype=np.int64, count=len(indices))
+    ref = np.fromiter((local_index[pairs[i][1]] for i in indices), dtype=np.int64, count=len(indices))
+    mov = np.fromiter((local_index[pairs[i][2]] for i in indices), dtype=np.int64, count=len(indices))
+    pending = []
+    # both directions are enqueued before either is read back (one host round trip for the two batches)
+    for kind, origins, ov in ((PAIR_H, placement.horizontal_crop_origins, max_x_overlap),
+                              (PAIR_V, placement.vertical_crop_origins, max_y_overlap)):
+        slots = np.flatnonzero(kinds == kind)
+        if not len(slots):
             continue
-        rows, n0, n1 = [], 0, 0
-        for k in slots:
-            _, a, b = pairs[indices[k]]
-            p, n0, n1 = make(local_index[a], local_index[b], height, width, int(ov))
-            rows.append(p)
-        shifts, err, _ = register_pairs(tiles, np.array(rows, dtype=native.PAIR_DTYPE), n0, n1, 10, normalization, minmax)
+        n0, n1, (ry, rx), (my, mx) = origins(height, width, int(ov))
+        recs = np.zeros(len(slots), dtype=native.PAIR_DTYPE)
+        for name, values in zip(native.PAIR_DTYPE.names, (ref[slots], mov[slots], ry, rx, my, mx)):
+            recs[name] = values
+        pending.append((slots, native.register_pairs_async(tiles, minmax, recs, n0, n1, 10, code)))
+    for slots, job in pending:
+        shifts, err, _ = shifts_from_results(job.fetch(), 10)
         out[slots, 0:2] = shifts
         out[slots, 2] = err
     return out
@@ -322,32 +330,34 @@ def pair_table_medians(pairs, table: np.ndarray, height: int, width: int, max_x_
     S-Pattern the rows of the centre row's parity give h_shift and the others h_shift_rev (:486-496).  Pure host
     arithmetic on the gathered table, so every rank arrives at the same integers.  Returns only the keys a pair
     was found for (a grid of one row has no v_shift), like the reference leaves the others at their defaults."""
-    def median_int(values):
-        return int(np.sort(np.asarray(values))[(len(values) - 1) // 2])
+    def med2(rows):      # per-axis LOWER median of [k, 2] integers
+        srt = np.sort(rows, axis=0)
+        return (int(srt[(len(rows) - 1) // 2, 0]), int(srt[(len(rows) - 1) // 2, 1]))
 
-    def med2(rows):
-        return (median_int([s[0] for s in rows]), median_int([s[1] for s in rows]))
-
-    h_n1 = placement.horizontal_crop_origins(height, width, int(max_x_overlap))[1] if any(p[0] == PAIR_H for p in pairs) else 0
-    v_n0 = placement.vertical_crop_origins(height, width, int(max_y_overlap))[0] if any(p[0] == PAIR_V for p in pairs) else 0
+    table = np.asarray(table, dtype=np.float64).reshape(len(pairs), -1)
+    kinds = np.fromiter((p[0] for p in pairs), dtype=np.int64, count=len(pairs))
+    ref_row = np.fromiter((p[1][0] for p in pairs), dtype=np.int64, count=len(pairs))
+    h_n1 = placement.horizontal_crop_origins(height, width, int(max_x_overlap))[1] if (kinds == PAIR_H).any() else 0
+    v_n0 = placement.vertical_crop_origins(height, width, int(max_y_overlap))[0] if (kinds == PAIR_V).any() else 0
     cy = (n_rows - 1) // 2
     s_pattern = scan_pattern == 'S-Pattern'
-    fwd, rev, ver = [], [], []
-    for (kind, a, _), row in zip(pairs, np.asarray(table, dtype=np.float64)):
-        if not (np.isfinite(row[0]) and np.isfinite(row[1])):
-            continue
-        if kind == PAIR_H:
-            s = horizontal_shift_from(row[:2], h_n1)
-            (rev if (s_pattern and a[0] % 2 != cy % 2) else fwd).append(s)
-        else:
-            ver.append(vertical_shift_from(row[:2], v_n0))
+    found = np.isfinite(table[:, 0]) & np.isfinite(table[:, 1])
+    # python round() of a float64 and numpy.rint round halves to even alike (horizontal_shift_from / vertical_shift_from,
+    # stitcher.py:511,524, for the whole table at once)
+    clean = np.where(found[:, None], table[:, :2], 0.0)
+    h_all = np.stack([np.rint(clean[:, 0]), np.rint(clean[:, 1] - h_n1)], axis=1).astype(np.int64)
+    v_all = np.stack([np.rint(clean[:, 0] - v_n0), np.rint(clean[:, 1])], axis=1).astype(np.int64)
+    is_rev = s_pattern & (ref_row % 2 != cy % 2)
+    fwd = h_all[found & (kinds == PAIR_H) & ~is_rev]
+    rev = h_all[found & (kinds == PAIR_H) & is_rev]
+    ver = v_all[found & (kinds == PAIR_V)]
     out = {}
-    if fwd:
+    if len(fwd):
         out['h_shift'] = med2(fwd)
-    if rev:
+    if len(rev):
         out['h_shift_rev'] = med2(rev)
         out['h_shift_rev_odd'] = int(cy % 2 == 0)
-    if ver:
+    if len(ver):
         out['v_shift'] = med2(ver)
     return out
 
