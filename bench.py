@@ -85,6 +85,10 @@ def main():
     ap.add_argument('--layout', choices=['arena', 'separate'], default='arena',
                     help="'arena' (default): canvas slots and tile stacks interleaved in ONE allocation, so that the canvas planes "
                          "are spread over all the memory the job holds; 'separate': one allocation each (round 2)")
+    ap.add_argument('--registration-stream', choices=['side', 'main'], default='main',
+                    help="region workloads: the next region's centre-pair registration on the launch stream ahead of the fusion "
+                         "launch (default), or on a stream of its own beside the launch in flight (measured: the 0.3 ms it saves "
+                         "per step come back as a slower fusion launch, profiles/r03_exp_registration_stream.log)")
     ap.add_argument('--host-plan', action='store_true',
                     help="headline job: build the whole fusion plan on the host and upload it (round 2) instead of expanding the "
                          "spans into the work list on the device")
@@ -339,10 +343,20 @@ def run_region(ctx):
 
     serial = bool(os.environ.get('SQ_BENCH_SERIAL'))
 
+    # The next region's registration is a chain of small latency-bound kernels on three tiles: on the launch stream it
+    # sits between two fusion launches with the chip idle around it (~0.45 ms per step); on a stream of its own its few
+    # workgroups run beside the fusion launch in flight (regions are independent) -- which then takes 0.03-0.28 ms longer:
+    # 26.59 / 26.85 against 26.86 / 26.88 ms per step on one box.  Kept as an option; the default leaves the launch alone.
+    reg_stream = torch.cuda.Stream(device=dev) if args.registration_stream == 'side' else None
+
     def start_registration():
         # registration: centre pairs on the registration plane (stitcher.py:422-498), enqueued only
-        return registration.register_grid_center_async(reg_plane, g, g, xs, ys, spec.pixel_size_um,
-                                                       spec.pixel_binning, normalization='phase')
+        if reg_stream is None:
+            return registration.register_grid_center_async(reg_plane, g, g, xs, ys, spec.pixel_size_um,
+                                                           spec.pixel_binning, normalization='phase')
+        with torch.cuda.stream(reg_stream):
+            return registration.register_grid_center_async(reg_plane, g, g, xs, ys, spec.pixel_size_um,
+                                                           spec.pixel_binning, normalization='phase')
 
     def step(record, pending, more):
         """One region: collect its registration, all-gather, geometry + span plan, one fusion launch.  Regions
@@ -715,8 +729,9 @@ def run_job(ctx):
         'ms_per_step': round(seconds / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'first_job_ms': round(first_job * 1e3, 3), 'steady_job_ms': None if steady is None else round(steady * 1e3, 3),
-        'first_job_note': 'the first timed job builds and uploads the fusion plan (cache emptied after the warm-up); the later ones '
-                          're-use it while the shifts stay; ms_per_step is the mean over ALL timed jobs, the first included',
+        'first_job_note': 'the first timed job builds the fusion plan (cache emptied after the warm-up: host sweep into spans + work list '
+                          'expanded on the device, or --host-plan: host planner + upload); the later ones re-use it while the shifts '
+                          'stay; ms_per_step is the mean over ALL timed jobs, the first included',
         'host_ms_per_job_rank0': {k: round(float(np.mean(v[args.warmup:])) * 1e3, 3) for k, v in lap.items()},
         'config': {'workload': wl['desc'], 'planes_total': total_planes, 'planes_per_gpu': len(mine),
                    'registration': (f'all {len(pairs)} adjacent pairs of the registration plane, dealt over the ranks in contiguous runs '
