@@ -98,7 +98,10 @@ def main():
                     help='cfg4: write {plane: position-weighted digest of its fused canvas} of the last step to this JSON '
                          'file (one file per rank, ".rankR" appended); for the N-rank == 1-rank check, not for timing')
     ap.add_argument('--traffic-bytes', type=float, default=None,
-                    help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else the committed measurement)')
+                    help='HBM bytes per fusion launch from a separate rocprofv3 --pmc pass (else measured live, see --no-live-traffic)')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help="N = 1 default workload: do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this launch "
+                         "after the timed region; roofline.traffic then carries the last committed measurement, labelled as such")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -144,10 +147,62 @@ def main():
             raise SystemExit(f"workload {name} on {world} GPUs is a weak-scaling run (one region per rank): pass --weak, "
                              "or use the default workload (cfg4, strong scaling)")
         out = run_region(ctx)
+        if world == 1 and args.workload is None and not args.planes and args.traffic_bytes is None and not args.no_live_traffic:
+            torch.cuda.empty_cache()          # the passes are child processes of their own: they need the HBM this one held
+            live = live_traffic(n_planes=wl['channels'] * wl['nz'])
+            if live is not None:
+                out['roofline']['traffic'], out['roofline']['traffic_source'] = live
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# roofline.traffic, measured: HBM bytes of the fusion launch from the PMC counters
+# ------------------------------------------------------------------------------------------------------------
+def live_traffic(n_planes, timeout_s=240):
+    """HBM bytes per fusion launch of THIS workload on THIS box: two short child runs of this script (2 steps after 1
+    warm-up, no CPU leg, no headline job) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, the
+    program directly after `--`, no trace domains beside the counters, as the guide's HBM section prescribes -- after the
+    timed region, outside every timing.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) KB per launch: gfx950 reports half the
+    bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM / rocprofv3).  Returns (bytes, source) or None when the
+    profiler is missing, the process is itself being profiled, or a pass fails (the caller keeps the committed number)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None or os.environ.get('SQ_BENCH_PMC_CHILD') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return None
+    env = dict(os.environ, SQ_BENCH_PMC_CHILD='1', SQ_BENCH_NO_REFERENCE_JOB='1', TMPDIR='/tmp')
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-live-traffic']
+    kb = {}
+    with tempfile.TemporaryDirectory(prefix='sq_pmc_', dir='/tmp') as tmp:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '-o', 'run', '--'] + child
+            try:
+                done = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except (OSError, subprocess.TimeoutExpired) as exc:
+                print(f'[bench] live traffic: {counter} pass did not finish ({exc}); keeping the committed measurement', file=sys.stderr)
+                return None
+            files = glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True)
+            if done.returncode != 0 or not files:
+                print(f'[bench] live traffic: {counter} pass failed (rc {done.returncode}); keeping the committed measurement: '
+                      f'{done.stderr.decode(errors="replace")[-300:]}', file=sys.stderr)
+                return None
+            with open(files[0]) as fh:
+                vals = [float(r['Counter_Value']) for r in csv.DictReader(fh)
+                        if 'fuse_overwrite' in r['Kernel_Name'] and r['Counter_Name'] == counter]
+            if not vals:
+                return None
+            kb[counter] = (sum(vals) / len(vals), len(vals))
+    traffic = (2.0 * kb['FETCH_SIZE'][0] + kb['WRITE_SIZE'][0]) * 1024.0
+    return traffic, (f"measured after the timed region on this box: two child runs of this command (--steps 2 --warmup 1) under rocprofv3 "
+                     f"--pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over {kb['FETCH_SIZE'][1]} / {kb['WRITE_SIZE'][1]} launches of "
+                     f"{n_planes} planes: (2 x {kb['FETCH_SIZE'][0]:.0f} + {kb['WRITE_SIZE'][0]:.0f}) KB")
 
 
 # ------------------------------------------------------------------------------------------------------------

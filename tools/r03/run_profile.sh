@@ -5,8 +5,8 @@ set -o pipefail
 mkdir -p gpurun_out/r3
 export TMPDIR=/tmp
 O=gpurun_out/r3
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-S="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-traffic"
+S="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic"
 export SQ_BENCH_NO_REFERENCE_JOB=1
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_tcc
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $B > $O/bench_under_rocprof.json 2> $O/prof.err || { echo rocprof failed; tail -5 $O/prof.err; exit 1; }
