@@ -66,6 +66,32 @@ int main(void) {
         for (int y = 0; y < TH; ++y) for (int x = 0; x < TW; ++x) { uint32_t v = tiles[t][y][x]; if (v < lo) lo = v; if (v > hi) hi = v; }
         if (mm[2 * t] != lo || mm[2 * t + 1] != hi) { printf("minmax of tile %d differs\n", t); return 5; }
     }
+    /* the same plan with its work list produced on the device: the table must be the exported one byte for byte */
+    {
+        sq_fuse_plan *spans = sq_fuse_plan_create_spans(rects, N, TH, TW, HC, WC, SQ_FUSE_OVERWRITE);
+        if (!spans) { printf("spans plan: %s\n", sq_last_error()); return 7; }
+        if (sq_fuse_plan_table_bytes(spans) != nbytes) { printf("spans plan: table size differs\n"); return 7; }
+        int64_t sbytes = sq_fuse_plan_expand_scratch_bytes(spans);
+        if (sbytes < 0) { printf("scratch: %s\n", sq_last_error()); return 7; }
+        void *d_table2, *d_scratch;
+        CHECK_HIP(hipMalloc(&d_table2, (size_t)nbytes));
+        CHECK_HIP(hipMalloc(&d_scratch, (size_t)(sbytes ? sbytes : 1)));
+        sq_fuse_args b = a;
+        b.plan = spans; b.table_dev = d_table2;
+        if (sq_fuse_planes(&b, stream) != SQ_ERR_INVALID || !strstr(sq_last_error(), "sq_fuse_plan_expand")) { printf("unexpanded plan accepted\n"); return 7; }
+        CHECK_SQ(sq_fuse_plan_expand(spans, d_table2, nbytes, d_scratch, sbytes, stream));
+        void *table2 = malloc((size_t)nbytes);
+        CHECK_HIP(hipMemcpy(table2, d_table2, (size_t)nbytes, hipMemcpyDeviceToHost));
+        if (memcmp(table, table2, (size_t)nbytes) != 0) { printf("device-expanded table differs from the host planner's\n"); return 7; }
+        CHECK_HIP(hipMemset(d_canvas, 0x55, sizeof want));
+        CHECK_SQ(sq_fuse_planes(&b, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_HIP(hipMemcpy(got, d_canvas, sizeof got, hipMemcpyDeviceToHost));
+        if (memcmp(got, want, sizeof want) != 0) { printf("canvas through the device-expanded plan differs\n"); return 7; }
+        sq_fuse_plan_destroy(spans);
+        free(table2);
+        hipFree(d_table2); hipFree(d_scratch);
+    }
     /* error path: a wrong canvas size must be refused with a message, not crash */
     a.canvas_w = WC + 1;
     if (sq_fuse_planes(&a, stream) != SQ_ERR_INVALID || !strstr(sq_last_error(), "geometry differs")) { printf("bad error path\n"); return 6; }
