@@ -673,7 +673,7 @@ def run_job(ctx):
                 raise RuntimeError(f"registration returned {shifts}, canvas {h_px}x{w_px} != planned {hc}x{wc}")
             plans.clear()
             # host: the sweep into spans; items, seam owners and their order are produced on the device (the GPU is idle
-            # here: registration has just been read back) -- 2.1 instead of 5.9 ms for this grid, csrc/plan_expand.hip
+            # here: registration has just been read back) -- 1.5 instead of 5.9 ms for this grid, csrc/plan_expand.hip
             plans[key] = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_OVERWRITE, expand_on_device=not args.host_plan)
             plans[key].device_table(dev)          # the expansion (or upload) belongs to the job that needed the plan
         return plans[key]

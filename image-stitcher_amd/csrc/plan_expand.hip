@@ -4,7 +4,7 @@
 // cuts the spans into ~300 000 items, finds each item's left neighbour, and sorts the list into the per-XCD lanes
 // the fusion kernel's queues walk: 4 ms more on a few host threads plus a 14.7 MB upload, paid by the first job of a
 // run (and by every region of a per-region-registration run).  Everything after the sweep is per-item work with no
-// dependence between items beyond two lookups, so here it runs as four kernels on the spans the host uploads
+// dependence between items beyond two lookups, so here it runs as a handful of kernels on the spans the host uploads
 // (~100 KB); the table they leave in device memory is the host planner's BYTE FOR BYTE (tests compare the two).
 //
 //   expand_items_kernel   item i -> its span (binary search in the spans' first item numbers), row step and column
@@ -13,8 +13,8 @@
 //                         hash table (the canvas is partitioned: keys are unique)
 //   seam_owners_kernel    item J looks up the item I that ends where J begins on the same first row; same height and
 //                         both a line wide: J owns the seam (Seam in common.h), I leaves its tail line
-//   bucket_tables_kernel  exclusive scan of the histograms over the workgroups (the STABLE rank of a workgroup's first
-//                         item of each bucket), bucket starts, the lanes' lengths, header.lane_items
+//   bucket_scan_kernel    exclusive scan of the histograms over the workgroups (the STABLE rank of a workgroup's first
+//                         item of each bucket); bucket_tables_kernel: bucket starts, the lanes' lengths, header.lane_items
 //   place_items_kernel    rank of every item inside its bucket in list order (wave by wave, ballots), its final position
 //                         (lane-interleaved like plan.cpp's order 2), item and seam record written there
 #include <hip/hip_runtime.h>
@@ -46,7 +46,7 @@ struct ExpandParams {
     int32_t *hvals;
     uint32_t hmask;
     int32_t *block_hist;     // [n_blocks][nblk]: counts, then (bucket_tables_kernel) ranks of the block's first items
-    int64_t *tables;         // start[nblk + 1] | lane_base[nblk] | tail_at[NX] | common
+    int64_t *tables;         // count[nblk] | start[nblk + 1] | lane_base[nblk] | tail_at[NX] | common
     Item *dst;
     Seam *dst_seam;
     TableHeader *header_dev;
@@ -145,23 +145,39 @@ __global__ __launch_bounds__(EXPAND_THREADS) void seam_owners_kernel(ExpandParam
     }
 }
 
-__global__ __launch_bounds__(MAX_BUCKETS) void bucket_tables_kernel(ExpandParams P) {
-    __shared__ int64_t count[MAX_BUCKETS];
-    const int k = threadIdx.x;
-    if (k < P.nblk) {
-        int64_t run = 0;
-        for (int b = 0; b < P.n_blocks; ++b) {
-            int32_t *h = &P.block_hist[(int64_t)b * P.nblk + k];
-            const int32_t c = *h;
-            *h = (int32_t)run;      // -> rank of the block's first item of bucket k
-            run += c;
-        }
-        count[k] = run;
-    }
+// one workgroup per bucket: exclusive scan of the bucket's counts over the item blocks, in place (a block's entry becomes
+// the stable rank of its first item of the bucket), and the bucket's total.  (One THREAD per bucket walking the ~1 200
+// blocks was 0.30 of the expansion's 0.46 ms: a chain of dependent loads.)
+__global__ __launch_bounds__(EXPAND_THREADS) void bucket_scan_kernel(ExpandParams P) {
+    __shared__ int64_t part[EXPAND_THREADS];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int per = (P.n_blocks + EXPAND_THREADS - 1) / EXPAND_THREADS;
+    const int b0 = min(tid * per, P.n_blocks), b1 = min(b0 + per, P.n_blocks);
+    int64_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += P.block_hist[(int64_t)b * P.nblk + k];
+    part[tid] = sum;
     __syncthreads();
-    if (k == 0) {      // a few hundred buckets: one thread, plan.cpp's arithmetic line by line
+    for (int off = 1; off < EXPAND_THREADS; off <<= 1) {      // inclusive scan of the threads' sums
+        const int64_t add = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - sum;
+    for (int b = b0; b < b1; ++b) {
+        int32_t *h = &P.block_hist[(int64_t)b * P.nblk + k];
+        const int32_t c = *h;
+        *h = (int32_t)run;
+        run += c;
+    }
+    if (tid == EXPAND_THREADS - 1) P.tables[k] = part[tid];      // count[k]
+}
+
+__global__ void bucket_tables_kernel(ExpandParams P) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {      // a few hundred buckets: one thread, plan.cpp's arithmetic line by line
         const int nblk = P.nblk;
-        int64_t *start = P.tables, *lane_base = start + nblk + 1, *tail_at = lane_base + nblk, *common_out = tail_at + NX;
+        const int64_t *count = P.tables;
+        int64_t *start = P.tables + nblk, *lane_base = start + nblk + 1, *tail_at = lane_base + nblk, *common_out = tail_at + NX;
         start[0] = 0;
         for (int b = 0; b < nblk; ++b) start[b + 1] = start[b] + count[b];
         int64_t lane_len[NX] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void place_items_kernel(ExpandParam
     }
     if (!live) return;
     const int nblk = P.nblk;
-    const int64_t *start = P.tables, *lane_base = start + nblk + 1, *tail_at = lane_base + nblk;
+    const int64_t *start = P.tables + nblk, *lane_base = start + nblk + 1, *tail_at = lane_base + nblk;
     const int64_t common = tail_at[NX];
     int64_t pos;
     if (k == nblk - 1) {
@@ -251,7 +267,7 @@ ExpandScratch expand_scratch(const sq_fuse_plan *plan) {
     S.hkeys = take((int64_t)slots * 8);
     S.hvals = take((int64_t)slots * 4);
     S.hist = take((int64_t)S.n_blocks * S.nblk * 4);
-    S.tables = take((int64_t)(2 * S.nblk + 1 + NX + 1) * 8);
+    S.tables = take((int64_t)(3 * S.nblk + 1 + NX + 1) * 8);
     S.total = off;
     return S;
 }
@@ -306,7 +322,8 @@ extern "C" int sq_fuse_plan_expand(sq_fuse_plan *plan, void *table_dev, int64_t 
             P.n_blocks = S.n_blocks;
             hipLaunchKernelGGL(expand_items_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
             hipLaunchKernelGGL(seam_owners_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
-            hipLaunchKernelGGL(bucket_tables_kernel, dim3(1), dim3(MAX_BUCKETS), 0, stream, P);
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(S.nblk), dim3(EXPAND_THREADS), 0, stream, P);
+            hipLaunchKernelGGL(bucket_tables_kernel, dim3(1), dim3(64), 0, stream, P);
             hipLaunchKernelGGL(place_items_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
             e = hipGetLastError();
             // the one number the host needs back: how much of the list is lane-interleaved (sq_fuse_planes reads it from
