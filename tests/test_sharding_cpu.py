@@ -313,3 +313,48 @@ def test_bench_arena_layout_views_do_not_alias():
     t2, c2 = bench.alloc_planes(n, g, hc, wc, 'cpu', 'separate')
     assert t2.is_contiguous() and tuple(t2.shape) == tuple(tiles.shape) and tuple(c2.shape) == tuple(canvas.shape)
     assert bench.tile_pointer_table(t2, range(n), order, 'cpu').tolist() == [t2[k].data_ptr() for k in range(n)]
+
+
+def test_bench_live_traffic_reads_the_pmc_passes(monkeypatch, tmp_path):
+    """bench.py's roofline.traffic: two child passes under `rocprofv3 --pmc` (one counter each, the program directly
+    after `--`), bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB averaged over the fusion launches.  Driven here with a stand-in
+    profiler that writes the counter table rocprofv3 writes."""
+    import importlib.util
+    import stat
+    spec = importlib.util.spec_from_file_location('bench_for_test2', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / 'bin' / 'rocprofv3'
+    fake.parent.mkdir()
+    fake.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+assert a[0] == '--pmc' and a[1] in ('FETCH_SIZE', 'WRITE_SIZE') and a[2] != '--kernel-trace', a
+split = a.index('--')
+prog = a[split + 1:]
+assert os.path.basename(prog[0]).startswith('python') and prog[1].endswith('bench.py') and '--no-live-traffic' in prog, prog
+assert not any(x in a[:split] for x in ('-s', '--sys-trace', '-r', '--runtime-trace', '--hip-trace', '--hsa-trace')), a
+assert os.environ.get('SQ_BENCH_PMC_CHILD') == '1' and os.environ.get('SQ_BENCH_NO_REFERENCE_JOB') == '1'
+d = os.path.join(a[a.index('-d') + 1], 'host', '123')
+os.makedirs(d)
+per_launch = {'FETCH_SIZE': (40.0e6, 42.0e6, 44.0e6), 'WRITE_SIZE': (83.0e6, 83.0e6, 83.0e6)}[a[1]]
+with open(os.path.join(d, 'run_counter_collection.csv'), 'w') as fh:
+    fh.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\\n')
+    fh.write(f'1,"synth_kernel<unsigned short>","{a[1]}",5.0\\n')
+    for k, v in enumerate(per_launch):
+        fh.write(f'{k + 2},"void (anonymous namespace)::fuse_overwrite_zg_kernel<float, true>(FuseParams, long)","{a[1]}",{v}\\n')
+''')
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv('PATH', str(fake.parent) + os.pathsep + os.environ['PATH'])
+    for k in [k for k in os.environ if k.startswith(('ROCPROF', 'ROCP_'))] + ['SQ_BENCH_PMC_CHILD']:
+        monkeypatch.delenv(k, raising=False)
+    traffic, source = bench.live_traffic(n_planes=40)
+    assert traffic == (2 * 42.0e6 + 83.0e6) * 1024
+    assert 'FETCH_SIZE' in source and '3 / 3 launches of 40 planes' in source
+    # a process that is itself a PMC child (or being profiled) does not start passes of its own
+    monkeypatch.setenv('SQ_BENCH_PMC_CHILD', '1')
+    assert bench.live_traffic(n_planes=40) is None
+    monkeypatch.delenv('SQ_BENCH_PMC_CHILD')
+    # a failing pass leaves the caller with the committed measurement
+    fake.write_text('#!/bin/sh\nexit 7\n')
+    assert bench.live_traffic(n_planes=40) is None
