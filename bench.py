@@ -161,7 +161,7 @@ def main():
 # ------------------------------------------------------------------------------------------------------------
 # roofline.traffic, measured: HBM bytes of the fusion launch from the PMC counters
 # ------------------------------------------------------------------------------------------------------------
-def live_traffic(n_planes, timeout_s=240):
+def live_traffic(n_planes, timeout_s=120):
     """HBM bytes per fusion launch of THIS workload on THIS box: two short child runs of this script (2 steps after 1
     warm-up, no CPU leg, no headline job) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, the
     program directly after `--`, no trace domains beside the counters, as the guide's HBM section prescribes -- after the
