@@ -239,6 +239,8 @@ struct Axis {
     const cplx *w;         // chirp w[j] = exp(-i pi j^2 / n), j < n  (Bluestein)
     const cplx *spec;      // FFT_m of conj(w) laid out circularly, in the order the forward m-point transform leaves it
     const int *perm;       // mixed-radix direct transform: frequency k sits at position perm[k]; else NULL (identity)
+    int rev_bits;          // > 0: a power of two transformed directly -- the kernels that fill a line put element j at the
+                           // bit-reversed position (put_pos) and lines_fft<.., PRE = true> skips its reversal pass; else 0
 };
 
 __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
@@ -253,10 +255,15 @@ __device__ __forceinline__ Axis axis_of(const RegParams &P, int axis) {
     X.w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
     X.spec = reinterpret_cast<const cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
     X.perm = (!X.m && X.pl.nf) ? reinterpret_cast<const int *>(P.ws + (axis ? L.perm1 : L.perm0)) : nullptr;
+    X.rev_bits = (!X.m && !X.pl.nf && X.n >= 2) ? 31 - __clz(X.n) : 0;
     return X;
 }
 // where frequency k of a transformed line sits (and where it has to be put before the second transform)
 __device__ __forceinline__ int pos_of(const Axis &X, int k) { return X.perm ? X.perm[k] : k; }
+// where a kernel that fills a line for lines_fft<.., PRE = true> puts the element that belongs at position p: the
+// power-of-two transform starts with a bit-reversal pass over the whole line (an LDS round trip and a barrier), which a
+// store to the reversed position in the first place makes unnecessary
+__device__ __forceinline__ int put_pos(const Axis &X, int p) { return X.rev_bits ? (int)(__brev((unsigned)p) >> (32 - X.rev_bits)) : p; }
 
 // A pair whose tile index or crop origin would read outside its tile never touches memory: its crops
 // are taken as zero and its result carries coarse = INT32_MIN (the pair table lives in device memory,
@@ -292,20 +299,22 @@ __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
 // (The half twiddle table copied into LDS per block -- ds_read instead of L1-cached global loads -- was built and
 // measured in round 3: 1 984 pairs of 1024 x 256 in 33.3 instead of 30.0 ms, 42-44 k instead of 46-50 k pairs/s in
 // 30-pair batches.  The table is L1-resident; the LDS copy only costs occupancy and LDS bandwidth.  Not kept.)
-template <bool INV>
+template <bool INV, bool PRE = false>
 __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
     const int logn = 31 - __clz(n);
-    for (int e = tid; e < nlines * n; e += nt) {
-        const int i = e & (n - 1);
-        const int j = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
-        if (i < j) {
-            cplx *x = base + (e - i);
-            const cplx a = x[i];
-            x[i] = x[j];
-            x[j] = a;
+    if (!PRE) {      // (PRE: the caller stored the line bit-reversed already, put_pos)
+        for (int e = tid; e < nlines * n; e += nt) {
+            const int i = e & (n - 1);
+            const int j = logn ? (int)(__brev((unsigned)i) >> (32 - logn)) : 0;
+            if (i < j) {
+                cplx *x = base + (e - i);
+                const cplx a = x[i];
+                x[i] = x[j];
+                x[j] = a;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     int s = 1;
     if (logn & 1) {   // odd number of stages: the first one alone (twiddle 1)
         for (int e = tid; e < nlines * (n >> 1); e += nt) {
@@ -329,13 +338,20 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
             // one table read per butterfly: (k + half) ts2 = k ts2 + n / 4 and k ts1 = 2 k ts2, so w3 = -i w2 (+i inverse)
             // and w1 = w2^2 -- the reads go through the L1 at 16 cycles per wave (three of them were 2.3e7 of the column
             // kernel's 2.7e7 vector memory reads per 992-pair batch), the square is four VALU operations
-            const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = rot90<INV>(w2), w1 = cmul(w2, w2);
             const cplx x0 = x[0], x1 = x[half], x2 = x[2 * half], x3 = x[3 * half];
-            // stage s: (x0, x1) and (x2, x3), both with w1
-            const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
-            const cplx a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
-            // stage s + 1: (a0, a2) with w2, (a1, a3) with w3
-            const cplx u2 = cmul(w2, a2), u3 = cmul(w3, a3);
+            cplx a0, a1, a2, a3, u2, u3;
+            if (half == 1) {      // the first pass of an even number of stages: k = 0, every twiddle is 1 or -i -- no table read, no product
+                a0 = cadd(x0, x1), a1 = csub(x0, x1), a2 = cadd(x2, x3), a3 = csub(x2, x3);
+                u2 = a2;
+                u3 = rot90<INV>(a3);
+            } else {
+                const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = rot90<INV>(w2), w1 = cmul(w2, w2);
+                // stage s: (x0, x1) and (x2, x3), both with w1
+                const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
+                a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
+                // stage s + 1: (a0, a2) with w2, (a1, a3) with w3
+                u2 = cmul(w2, a2), u3 = cmul(w3, a3);
+            }
             x[0] = cadd(a0, u2);
             x[2 * half] = csub(a0, u2);
             x[half] = cadd(a1, u3);
@@ -456,10 +472,10 @@ __device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__res
 // mixed-radix stage) -- the radix-13 butterfly alone holds 13 complex128 in registers, and a kernel that merely CONTAINS
 // it is allocated for it: the power-of-two kernels would drop from 8+ to 2 waves per SIMD (measured: 1 984 pairs of
 // 1024 x 256 in 57 instead of 29 ms)
-template <bool INV, bool BWD, bool GEN>
+template <bool INV, bool BWD, bool GEN, bool PRE = false>
 __device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
     if (GEN && pl.nf) lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
-    else lines_fft_pow2<INV>(base, pl.len, nlines, tw, tid, nt);
+    else lines_fft_pow2<INV, PRE>(base, pl.len, nlines, tw, tid, nt);
 }
 
 // Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
@@ -476,11 +492,13 @@ __device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cpl
 //   BWD = false ("first" transform): natural-order input  -> frequency k at position pos_of(X, k);
 //   BWD = true  ("second"):          input with frequency k at pos_of(X, k) -> natural-order output.
 // pos_of is the identity except for a mixed-radix direct transform.
-template <bool INV, bool BWD, bool GEN>
+// PRE: the caller has filled the lines through put_pos (it matters for a directly transformed power of two only)
+template <bool INV, bool BWD, bool GEN, bool PRE = false>
 __device__ void lines_fft(cplx *base, const Axis &X, int nlines, int tid, int nt) {
     const int n = X.n;
     if (!X.m) {
-        lines_fft_plan<INV, BWD, GEN>(base, nlines, X.tw, X.pl, tid, nt);
+        if (PRE && X.rev_bits) lines_fft_plan<INV, BWD, GEN, true>(base, nlines, X.tw, X.pl, tid, nt);
+        else lines_fft_plan<INV, BWD, GEN, false>(base, nlines, X.tw, X.pl, tid, nt);
         return;
     }
     const int M = X.m;
@@ -718,10 +736,10 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
         const int l = wi.l, j = wi.j;
         const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
         const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
-        x[(int64_t)l * ld + j] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+        x[(int64_t)l * ld + put_pos(X, j)] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
     }
     __syncthreads();
-    lines_fft<false, false, GEN>(x, X, nrow, tid, nt);
+    lines_fft<false, false, GEN, true>(x, X, nrow, tid, nt);
     Walk wo(tid, nt, n1h);
     for (int e = tid; e < nrow * n1h; e += nt, wo.next()) {
         const int l = wo.l, k = wo.j;
@@ -784,19 +802,19 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
     cplx *B = A + (int64_t)n0 * sp;
+    const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     Walk wl(tid, nt, ncol);
     for (int i = tid; i < n0 * ncol; i += nt, wl.next()) {
-        const int r = wl.l, c = wl.j;
-        f[(int64_t)c * n0 + r] = A[(int64_t)r * sp + c0 + c];
-        g[(int64_t)c * n0 + r] = B[(int64_t)r * sp + c0 + c];
+        const int r = wl.l, c = wl.j, at = put_pos(X, r);
+        f[(int64_t)c * n0 + at] = A[(int64_t)r * sp + c0 + c];
+        g[(int64_t)c * n0 + at] = B[(int64_t)r * sp + c0 + c];
     }
     __syncthreads();
-    const Axis X = axis_of(P, 0);   // a directly transformed axis here (power of two or smooth): ld == n0
     if (ncol == tc) {   // f and g are contiguous: one batch of 2 tc lines
-        lines_fft<false, false, GEN>(f, X, 2 * tc, tid, nt);
+        lines_fft<false, false, GEN, true>(f, X, 2 * tc, tid, nt);
     } else {
-        lines_fft<false, false, GEN>(f, X, ncol, tid, nt);
-        lines_fft<false, false, GEN>(g, X, ncol, tid, nt);
+        lines_fft<false, false, GEN, true>(f, X, ncol, tid, nt);
+        lines_fft<false, false, GEN, true>(g, X, ncol, tid, nt);
     }
     const double eps100 = 100.0 * 2.220446049250313e-16;
     double *amps = reinterpret_cast<double *>(P.ws + L.amps) + ((int64_t)pair * n1h + c0) * 2;
@@ -1003,10 +1021,10 @@ __global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
             b = cconj(q1[n1 - k]);
         }
         if (!two) b = {0.0, 0.0};
-        x[(int64_t)l * ld + pos_of(X, k)] = {a.re - b.im, a.im + b.re};   // a + i b, where the second transform wants frequency k
+        x[(int64_t)l * ld + put_pos(X, pos_of(X, k))] = {a.re - b.im, a.im + b.re};   // a + i b, where the second transform wants frequency k
     }
     __syncthreads();
-    lines_fft<true, true, GEN>(x, X, nline, tid, nt);
+    lines_fft<true, true, GEN, true>(x, X, nline, tid, nt);
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int l = wave; l < nline; l += nw) {
         const int y0 = 2 * (rp0 + l), y1 = min(y0 + 1, n0 - 1);
