@@ -325,6 +325,12 @@ def committed_traffic(workload, n_planes):
             if pm.get('workload') == workload and pm.get('planes') == n_planes:
                 return pm['traffic_bytes_per_launch'], f'profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of ' \
                     'this launch on another box; not measured in this run)'
+            if pm.get('workload') == workload and pm.get('planes') and n_planes:
+                # the same geometry with another number of planes per launch (the last batch of a rank's run is shorter):
+                # every plane moves the same bytes
+                return pm['traffic_bytes_per_launch'] * n_planes / pm['planes'], \
+                    f'profiles/{name} (rocprofv3 --pmc passes of a {pm["planes"]}-plane launch of this geometry on another box, ' \
+                    f'scaled to the {n_planes:g} planes of this run\'s mean launch; not measured in this run)'
         except (OSError, ValueError, KeyError):
             pass
     return None, 'not measured (no committed PMC pass for this workload / plane count)'
@@ -803,8 +809,8 @@ def run_job(ctx):
                            'head + event-clocked launches'},
         'roofline': {'bound': 'hbm', 'kernel': 'fuse_overwrite_zg_kernel (u16, f32 gains, plane groups)', 'achieved': round(achieved, 1),
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                     'traffic': committed_traffic(wl['name'], int(round(float(npl.mean()))))[0],
-                     'traffic_source': committed_traffic(wl['name'], int(round(float(npl.mean()))))[1],
+                     'traffic': committed_traffic(wl['name'], float(npl.mean()) if float(npl.mean()) % 1 else int(npl.mean()))[0],
+                     'traffic_source': committed_traffic(wl['name'], float(npl.mean()) if float(npl.mean()) % 1 else int(npl.mean()))[1],
                      'algorithmic_bytes_per_launch': int(alg * npl.mean()), 'launch_ms': round(float(ms.mean()), 4),
                      'frac_per_rank': [round(f, 4) for f in fracs], 'of_rank': 0},
         'parity': shift_parity(shifts, truth),
