@@ -617,10 +617,20 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
             c = atomicAdd(&P.queue[queue_of(given_up) * QUEUE_STRIDE], 1u);
         }
     };
+    // lds_written(): s_waitcnt lgkmcnt(0) by the wave that has just written the NEXT chunk's (queue, index) into LDS.  The
+    // barrier at the top of the loop is what publishes them, and a barrier only orders what has completed: the compiler
+    // (ROCm 7.2) puts the wait in front of the barrier after the descriptor stores below but NOT in front of the one at the
+    // top of the loop, which it reaches round the back edge straight after thread 0's ds_write -- the other waves could
+    // then read the slot before the write landed, i.e. the (queue, index) of two chunks ago: they repeated an old chunk
+    // (harmless) and skipped their share of the new one.  Found in round 3 as 28 ... 508 unwritten voxels in 1-2 % of the
+    // launches of the per-plane feather kernel on a small plan (tools/queue_stress.py; the plane-group kernels never
+    // showed it in thousands of launches, but their code had the same gap).
+    auto lds_written = [] { __builtin_amdgcn_s_waitcnt(0xc07f); };      // gfx9 encoding: lgkmcnt(0), vmcnt / expcnt untouched
     if (threadIdx.x == 0) {
         const Chunk first = settle(atomicAdd(&P.queue[queue_of(0) * QUEUE_STRIDE], 1u));
         s_q[0] = first.q;
         s_c[0] = first.c;
+        lds_written();
     }
     for (int iter = 0;; ++iter) {
         __syncthreads();
@@ -653,6 +663,7 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
             const Chunk nxt = pull ? settle(pending) : Chunk{-1, 0u};
             s_q[(iter + 1) & 1] = nxt.q;
             s_c[(iter + 1) & 1] = nxt.c;
+            lds_written();
         }
     }
 }
@@ -1374,17 +1385,19 @@ __device__ __forceinline__ float div_by_refined(float n, float d, float r) {   /
     return fmaf(fmaf(-d, q, n), r, q);
 }
 
-template <int FLAT, bool FULL>
+// OutT = uint16_t (round, clip, pack) or float (the blended value as it is: two 16-byte stores per 8 voxels)
+template <int FLAT, bool FULL, typename OutT = uint16_t>
 __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it, const int tid) {
     typedef uint16_t T;
     constexpr int VEC = 8;
+    constexpr bool F32OUT = sizeof(OutT) == 4;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
-    T *cplane[ZB];
+    OutT *cplane[ZB];
     const T *t0[ZB], *t1[ZB];
 #pragma unroll
     for (int z = 0; z < ZB; ++z) {
         const int zz = (FULL || z < gn) ? z : 0;
-        cplane[z] = static_cast<T *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
+        cplane[z] = static_cast<OutT *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
         t0[z] = sgpr(static_cast<const T *>(A.tile[zz]));
         t1[z] = sgpr(static_cast<const T *>(A.ltile[zz]));
     }
@@ -1394,8 +1407,8 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
     for (int idx = tid; idx < rows * G; idx += 256) {
         const int r = idx / G, j = idx - r * G;
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
-        // the planes of a group sit at the same phase of a 128-byte line, so also of 16 bytes
-        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (VEC - 1));
+        // the planes of a group sit at the same phase of a 128-byte line, so also of 16 (32) bytes
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(OutT)) & (VEC - 1));
         const int v = (mis ? 1 : 0) + j;
         if (v >= (n + mis) / VEC) continue;
         const int p0 = v * VEC - mis;
@@ -1431,7 +1444,7 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
 #pragma unroll
         for (int z = 0; z < ZB; ++z)
             if (FULL || z < gn) {
-                uint32_t k[VEC];
+                float o[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float va = (float)Pix<uint16_t>::get(ra[z], e), vb = (float)Pix<uint16_t>::get(rb[z], e);
@@ -1440,23 +1453,35 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
                         vb = div_by_refined(vb, g1[e], r1[e]);
                     }
                     const float acc = __fadd_rn(__fmul_rn(w0[e], va), __fmul_rn(w1[e], vb));
-                    k[e] = cvt_u32_sat(__builtin_rintf(div_by_refined(acc, ws[e], rw[e])));   // negative -> 0
+                    o[e] = div_by_refined(acc, ws[e], rw[e]);
                 }
-                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                u32x4 out;
+                if constexpr (F32OUT) {
+                    u32x4 lo, hi;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(k[2 * q], k[2 * q + 1]);   // saturates to 65535
-                    out[q] = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
+                    for (int q = 0; q < 4; ++q) {
+                        lo[q] = __float_as_uint(o[q]);
+                        hi[q] = __float_as_uint(o[4 + q]);
+                    }
+                    stg_nt(cplane[z] + doff + p0, lo);
+                    stg_nt(cplane[z] + doff + p0 + 4, hi);
+                } else {
+                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                    u32x4 out;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // round half to even, negative -> 0, pack saturates to 65535
+                        const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(__builtin_rintf(o[2 * q])), cvt_u32_sat(__builtin_rintf(o[2 * q + 1])));
+                        out[q] = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
+                    }
+                    stg_nt(cplane[z] + doff + p0, out);
                 }
-                stg_nt(cplane[z] + doff + p0, out);
             }
     }
     // the pixels before / after the 16-byte-aligned body of each row, one per thread and plane
     for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
         const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
-        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(T)) & (VEC - 1));
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(OutT)) & (VEC - 1));
         const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
         const int head_end = min(n, v_first * VEC - mis);
         const int tail_start = max(head_end, v_end * VEC - mis);
@@ -1482,7 +1507,9 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
                     vb = div_by_refined(vb, gb, fb);
                 }
                 const float acc = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
-                stg_s<T>(cplane[z] + doff + p, (T)min(cvt_u32_sat(__builtin_rintf(div_by_refined(acc, wsum, rws))), 65535u));
+                const float o = div_by_refined(acc, wsum, rws);
+                if constexpr (F32OUT) stg_s<OutT>(cplane[z] + doff + p, o);
+                else stg_s<OutT>(cplane[z] + doff + p, (OutT)min(cvt_u32_sat(__builtin_rintf(o)), 65535u));
             }
     }
 }
@@ -1492,9 +1519,10 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
 #ifndef SQ_WAVES_FEATHER_ZG
 #define SQ_WAVES_FEATHER_ZG 3
 #endif
-template <int FLAT, bool DYN>
+template <int FLAT, bool DYN, typename OutT = uint16_t>
 __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feather_zg_kernel(const FuseParams P, const int64_t n_items) {
     typedef uint16_t T;
+    constexpr bool F32OUT = sizeof(OutT) == 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = *P.n_groups;
@@ -1523,7 +1551,11 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
     auto body = [&](int, const Item &it, const UnitAux &A) {
         const int gn = sgpr(A.g.n);
         if (gn == 1) {
-            feather_one_item<T, T, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
+            feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
+        } else if (F32OUT && it.nref <= 1) {
+            // float32 canvas: nothing of a one-tile (or empty) item is shared between the planes but the geometry --
+            // the per-plane path (float(v) or v / g stored as it is), plane after plane
+            for (int z = 0; z < gn; ++z) feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[z]), it, wave, lane);
         } else if (it.nref <= 1) {
             Item one = it;
             one.a = sgpr(A.first.a);
@@ -1538,10 +1570,10 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
                 process_item_zg<false, 1>(P, A, gn, one, wave, lane);
             }
         } else if (it.nref == 2) {
-            if (gn == ZB) blend_item_zg<FLAT, true>(P, A, gn, it, threadIdx.x);
-            else blend_item_zg<FLAT, false>(P, A, gn, it, threadIdx.x);
+            if (gn == ZB) blend_item_zg<FLAT, true, OutT>(P, A, gn, it, threadIdx.x);
+            else blend_item_zg<FLAT, false, OutT>(P, A, gn, it, threadIdx.x);
         } else {
-            for (int z = 0; z < gn; ++z) blend_item<T, T, FLAT, true>(P, sgpr(A.g.plane[z]), it, threadIdx.x);
+            for (int z = 0; z < gn; ++z) blend_item<T, OutT, FLAT, true>(P, sgpr(A.g.plane[z]), it, threadIdx.x);
         }
     };
     if (DYN) {
@@ -1951,7 +1983,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (flat == 1) SQ_FEATHER_F(T, O, 1); \
         SQ_FEATHER_F(T, O, 2);           \
     } while (0)
-    if (u16 && !f32out && flat != 2 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS) &&
+    if (u16 && flat != 2 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS) &&
         std::min(a->tile_h, a->tile_w) <= BLEND_WSUM_MAX) {   // a weight is at most half the shorter tile side, a weight sum twice that
         // planes that share a gain image (every gain moderate), or that have none, go through the items together
         // (fuse_feather_zg_kernel)
@@ -1959,16 +1991,22 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
         PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
         hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 3u, a->n_planes,
-                           a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                           a->canvas_plane_stride * (int64_t)(f32out ? sizeof(float) : sizeof(uint16_t)), ZB, n_groups, groups,
                                (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
         P.groups = groups;
         P.n_groups = n_groups;
-        if (flat == 1) {
-            if (P.queue) return launch_zg(fuse_feather_zg_kernel<1, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-            return launch_zg(fuse_feather_zg_kernel<1, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+#define SQ_FEATHER_ZG(F, O)                                                                                                      \
+    do {                                                                                                                          \
+        if (P.queue) return launch_zg(fuse_feather_zg_kernel<F, true, O>, P, h.n_items, a->n_planes, stream, a->grid_blocks);    \
+        return launch_zg(fuse_feather_zg_kernel<F, false, O>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                \
+    } while (0)
+        if (f32out) {      // float32 canvas: the blended strips through the grouped blend, one-tile items plane after plane
+            if (flat == 1) SQ_FEATHER_ZG(1, float);
+            SQ_FEATHER_ZG(0, float);
         }
-        if (P.queue) return launch_zg(fuse_feather_zg_kernel<0, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-        return launch_zg(fuse_feather_zg_kernel<0, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+        if (flat == 1) SQ_FEATHER_ZG(1, uint16_t);
+        SQ_FEATHER_ZG(0, uint16_t);
+#undef SQ_FEATHER_ZG
     }
     if (u16) {
         if (f32out) SQ_FEATHER(uint16_t, float);

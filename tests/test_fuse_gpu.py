@@ -534,3 +534,51 @@ def test_seam_lines_have_one_writer(seed, queues, gdtype):
             assert (got[:, cw:] == 0x5A5A).all(), f'row padding of plane {p} touched (pitch {pitch})'
             assert (host[lead + p * stride + ch * pitch: lead + (p + 1) * stride] == 0x5A5A).all()
         assert (host[:lead] == 0x5A5A).all() and (host[lead + planes * stride:] == 0x5A5A).all()
+
+
+@pytest.mark.parametrize('seed', range(4))
+@pytest.mark.parametrize('queues', [False, True])
+def test_feather_plane_groups_with_a_float32_canvas(seed, queues):
+    """Feather mode into a float32 canvas with plane groups (round 3): the blended strips of the planes that share a
+    gain image go through the grouped blend (blend_item_zg<.., float>), one-tile items plane after plane.  1..12 planes
+    on 1..3 gain images (one with a gain that is not moderate: groups of one for its planes) or none: every plane equals
+    the oracle's float32 blend bit for bit, and the per-plane kernel (SQ_FUSE_NO_PLANE_GROUPS) gives the same."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5200 + seed)
+    th, tw = int(rng.integers(20, 70)), int(rng.integers(40, 260))
+    rows, cols = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+    oy, ox = int(rng.integers(2, th // 3)), int(rng.integers(2, tw // 3))
+    n = rows * cols
+    rects = np.zeros((n, 6), dtype=np.int64)
+    for r in range(rows):
+        for c in range(cols):
+            rects[r * cols + c] = (0, 0, th, tw, r * (th - oy) + c * 2, c * (tw - ox) + (rows - 1 - r) * 3)
+    ch = int(rects[:, 4].max() + th + rng.integers(0, 9))
+    cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
+    planes = int(rng.integers(2, 13))
+    tiles = rng.integers(0, 65536, size=(planes, n, th, tw)).astype(np.uint16)
+    gains = [np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float32) for _ in range(3)]
+    gains[1][rng.integers(0, th), rng.integers(0, tw)] = 2.0 ** -30      # not moderate: no grouped blend for its planes
+    use_gains = seed % 2 == 0
+    which = [int(rng.integers(0, 3)) for _ in range(planes)] if use_gains else [-1] * planes
+    if planes >= 7 and use_gains:
+        which[:6] = [0] * 6                                               # a full group of 5 and a leftover
+    d_gains = [torch.from_numpy(g).to(dev) for g in gains]
+    flats = [d_gains[k] for k in which] if use_gains else None
+    plan = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_FEATHER)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    grouped = native.empty_canvas(planes, ch, cw, torch.float32, dev)
+    grouped.fill_(-7.0)
+    single = native.empty_canvas(planes, ch, cw, torch.float32, dev)
+    single.fill_(-7.0)
+    native.fuse_planes(plan, d_tiles, grouped, flats, flags=flags)
+    native.fuse_planes(plan, d_tiles, single, flats, flags=flags | native.SQ_FUSE_NO_PLANE_GROUPS)
+    torch.cuda.synchronize()
+    for p in range(planes):
+        want = O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, gains[which[p]] if use_gains else None, out_dtype=np.float32)
+        for name, got in (('plane groups', grouped[p].cpu().numpy()), ('per-plane kernel', single[p].cpu().numpy())):
+            ys, xs = np.nonzero(got != want)
+            assert not len(ys), (f'{name}, plane {p} (gain image {which[p]}) of {planes}, canvas {ch}x{cw}, tiles {th}x{tw}: {len(ys)} voxels differ, first '
+                                 f'{[(int(y), int(x), float(got[y, x]), float(want[y, x])) for y, x in list(zip(ys, xs))[:10]]}')

@@ -1,0 +1,59 @@
+"""Stress of the device work queues on a SMALL plan (71 items x 12 planes, as many workgroups as the kernel keeps resident):
+hundreds of launches of each kernel family, every launch compared with the oracle on the device.  Round 3 found the
+per-plane feather kernel leaving 28 ... 508 voxels unwritten in 1-2 % of such launches: a missing LDS wait in front of
+the queue walk's loop-top barrier (csrc/fuse.hip, for_each_queued_item / lds_written)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_stitcher_amd import native
+from oracle import stitch_oracle as O
+dev = torch.device('cuda:0')
+seed, queues = 1, True
+rng = np.random.default_rng(5200 + seed)
+th, tw = int(rng.integers(20, 70)), int(rng.integers(40, 260))
+rows, cols = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+oy, ox = int(rng.integers(2, th // 3)), int(rng.integers(2, tw // 3))
+n = rows * cols
+rects = np.zeros((n, 6), dtype=np.int64)
+for r in range(rows):
+    for c in range(cols):
+        rects[r * cols + c] = (0, 0, th, tw, r * (th - oy) + c * 2, c * (tw - ox) + (rows - 1 - r) * 3)
+ch = int(rects[:, 4].max() + th + rng.integers(0, 9)); cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
+planes = int(rng.integers(2, 13))
+tiles = rng.integers(0, 65536, size=(planes, n, th, tw)).astype(np.uint16)
+print('th tw', th, tw, 'grid', rows, cols, 'ov', oy, ox, 'canvas', ch, cw, 'planes', planes); print(rects)
+plan = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_FEATHER)
+d_tiles = torch.from_numpy(tiles).to(dev)
+
+
+
+Q = native.SQ_FUSE_FORCE_QUEUES | native.SQ_FUSE_NO_PLANE_GROUPS
+plan_ow = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_OVERWRITE)
+want_f32 = torch.from_numpy(np.stack([O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None, out_dtype=np.float32) for p in range(planes)])).to(dev)
+want_u16 = torch.from_numpy(np.stack([O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None, out_dtype=np.uint16) for p in range(planes)]).astype(np.int32)).to(dev)
+want_ow = torch.from_numpy(np.stack([O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw) for p in range(planes)]).astype(np.int32)).to(dev)
+def run(name, pl, dtype, want, iters=600, sync_before=False, grid=0, flags=Q):
+    bad = 0
+    for it in range(iters):
+        a = native.empty_canvas(planes, ch, cw, dtype, dev)
+        if dtype == torch.float32: a.fill_(-7.0)
+        else: a.view(torch.int16).fill_(-7)
+        if sync_before: torch.cuda.synchronize()
+        native.fuse_planes(pl, d_tiles, a, None, flags=flags, grid_blocks=grid)
+        torch.cuda.synchronize()
+        got = a if dtype == torch.float32 else a.to(torch.int32)
+        n = int((got != want).sum())
+        if n:
+            bad += 1
+            if bad <= 2:
+                idx = (got != want).nonzero()[:6].tolist()
+                print(f'   {name} iter {it}: {n} wrong', [(i, float(got[tuple(i)]), float(want[tuple(i)])) for i in idx], flush=True)
+    print(f'{name}: {bad} of {iters} launches wrong', flush=True)
+run('feather per-plane float32, queues', plan, torch.float32, want_f32)
+run('feather per-plane uint16, queues', plan, torch.uint16, want_u16)
+run('overwrite per-plane uint16, queues', plan_ow, torch.uint16, want_ow)
+run('feather per-plane float32, queues, sync before launch', plan, torch.float32, want_f32, sync_before=True)
+run('feather per-plane float32, queues, 64 blocks', plan, torch.float32, want_f32, grid=64)
+run('feather per-plane float32, static', plan, torch.float32, want_f32, flags=native.SQ_FUSE_FORCE_STATIC | native.SQ_FUSE_NO_PLANE_GROUPS)
+run('feather GROUPED float32, queues', plan, torch.float32, want_f32, flags=native.SQ_FUSE_FORCE_QUEUES)
+run('overwrite GROUPED uint16, queues', plan_ow, torch.uint16, want_ow, flags=native.SQ_FUSE_FORCE_QUEUES)
