@@ -582,3 +582,35 @@ def test_feather_plane_groups_with_a_float32_canvas(seed, queues):
             ys, xs = np.nonzero(got != want)
             assert not len(ys), (f'{name}, plane {p} (gain image {which[p]}) of {planes}, canvas {ch}x{cw}, tiles {th}x{tw}: {len(ys)} voxels differ, first '
                                  f'{[(int(y), int(x), float(got[y, x]), float(want[y, x])) for y, x in list(zip(ys, xs))[:10]]}')
+
+
+@pytest.mark.parametrize('out_dtype', ['float32', 'uint16'])
+def test_device_queues_lose_no_work_on_small_launches(out_dtype):
+    """Regression test of the queue walk's LDS hazard (csrc/fuse.hip, for_each_queued_item / lds_written): a small
+    feather plan (71 items x 12 planes, one or two work units per workgroup) through the per-plane kernel with the device
+    queues, 300 launches, every one compared with the oracle on the device.  Before the fix 1-2 % of such launches left a
+    wave's share of an item unwritten (profiles/r03_queue_stress_before_fix.log)."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5201)
+    th, tw, rows, cols, oy, ox, planes = 29, 140, 3, 2, 5, 13, 12
+    rects = np.zeros((rows * cols, 6), dtype=np.int64)
+    for r in range(rows):
+        for c in range(cols):
+            rects[r * cols + c] = (0, 0, th, tw, r * (th - oy) + c * 2, c * (tw - ox) + (rows - 1 - r) * 3)
+    ch, cw = int(rects[:, 4].max() + th + 2), int(rects[:, 5].max() + tw + 7)
+    tiles = rng.integers(0, 65536, size=(planes, rows * cols, th, tw)).astype(np.uint16)
+    plan = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_FEATHER)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    tdt = torch.float32 if out_dtype == 'float32' else torch.uint16
+    want = np.stack([O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None, out_dtype=np.dtype(out_dtype)) for p in range(planes)])
+    d_want = torch.from_numpy(want.astype(np.float32)).to(dev)
+    wrong = []
+    for it in range(300):
+        canvas = native.empty_canvas(planes, ch, cw, tdt, dev)
+        canvas.view(torch.int16 if tdt == torch.uint16 else torch.float32).fill_(-7)
+        native.fuse_planes(plan, d_tiles, canvas, None, flags=native.SQ_FUSE_FORCE_QUEUES | native.SQ_FUSE_NO_PLANE_GROUPS)
+        n = int((canvas.to(torch.float32) != d_want).sum())
+        if n:
+            wrong.append((it, n))
+    assert not wrong, f'launches with wrong voxels (launch, voxels): {wrong[:10]}'
