@@ -13,7 +13,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp "$f" $O/kernel_stats.csv; head -8 $O/kernel_stats.csv; cat $O/bench_under_rocprof.json
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $S > $O/pmc_fetch.log 2>&1 || { echo pmc fetch failed; tail -5 $O/pmc_fetch.log; exit 1; }
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $S > $O/pmc_write.log 2>&1 || { echo pmc write failed; tail -5 $O/pmc_write.log; exit 1; }
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write cfg3 40 "round 3 HEAD (fuse.hip unchanged since round 2's last commit): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --steps 2 --warmup 1 --no-cpu-baseline" $O/pmc_traffic_latest.json
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write cfg3 40 "round 3 last build (queue walk with the explicit LDS wait): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --steps 2 --warmup 1 --no-cpu-baseline" $O/pmc_traffic_latest.json
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq -- $S > $O/pmc_sq.log 2>&1 || { echo pmc sq failed; tail -5 $O/pmc_sq.log; exit 1; }
 timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_tcc -- $S > $O/pmc_tcc.log 2>&1 || { echo pmc tcc failed; tail -5 $O/pmc_tcc.log; exit 1; }
 python - <<'PY'
