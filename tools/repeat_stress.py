@@ -67,6 +67,26 @@ for name, flags in (('plane groups, queues', native.SQ_FUSE_FORCE_QUEUES), ('per
         bad += int((canvas.to(torch.int32) != want).sum() > 0)
     report(f'overwrite fusion with gains, {name}, against the oracle', bad, REPS, t0)
 
+# --- the same over other block / unit ratios: tiny and mid-size grids, plane counts that leave partial groups, no gains / f64 gains
+for g2, th2, planes2, gkind in ((2, 64, 37, 'f32'), (3, 96, 5, 'none'), (8, 128, 13, 'f64'), (5, 160, 24, 'f32'), (1, 256, 11, 'none')):
+    t0 = time.perf_counter()
+    sh2 = placement.Shifts((2, -(th2 // 8)), (-(th2 // 9), -3)) if g2 > 1 else placement.Shifts()
+    wc2, hc2 = placement.canvas_size(g2, g2, th2, th2, use_registration=g2 > 1, shifts=sh2) if g2 > 1 else (th2, th2)
+    rects2 = placement.grid_rects(g2, g2, th2, th2, sh2) if g2 > 1 else np.array([(0, 0, th2, th2, 0, 0)])
+    tl2 = rng.integers(0, 65536, size=(planes2, g2 * g2, th2, th2)).astype(np.uint16)
+    fl2 = None if gkind == 'none' else (0.5 + rng.random((th2, th2))).astype(np.float32 if gkind == 'f32' else np.float64)
+    want2 = torch.from_numpy(np.stack([O.fuse_plane_overwrite(list(tl2[p]), rects2, hc2, wc2, fl2) for p in range(planes2)]).astype(np.int32)).to(dev)
+    d_tl2 = torch.from_numpy(tl2).to(dev)
+    d_fl2 = None if fl2 is None else [torch.from_numpy(fl2).to(dev)] * planes2
+    plan2 = native.FusePlan(rects2, th2, th2, hc2, wc2)
+    bad = 0
+    for _ in range(REPS):
+        canvas = native.empty_canvas(planes2, hc2, wc2, torch.uint16, dev)
+        canvas.view(torch.int16).fill_(-7)
+        native.fuse_planes(plan2, d_tl2, canvas, d_fl2, flags=native.SQ_FUSE_FORCE_QUEUES)
+        bad += int((canvas.to(torch.int32) != want2).sum() > 0)
+    report(f'overwrite fusion {g2}x{g2} grid of {th2}^2 tiles, {planes2} planes, gains {gkind}, plane groups + queues, against the oracle', bad, REPS, t0)
+
 # --- pyramid level and chunk encoder -------------------------------------------------------------------------------
 t0 = time.perf_counter()
 img = torch.from_numpy((2000 + (np.add.outer(np.arange(1500) * 3, np.arange(1900) * 2) // 4 + rng.integers(0, 8, (1500, 1900))) % 60000).astype(np.uint16)[None].repeat(2, 0)).to(dev)
