@@ -86,7 +86,7 @@ int sq_fuse_plan_export(const sq_fuse_plan *plan, void *host_buf, int64_t host_b
 int sq_fuse_plan_upload(const sq_fuse_plan *plan, void *table_dev, int64_t table_bytes, void *stream);
 /* The same plan with its work list produced ON THE DEVICE (overwrite mode; tiles up to 8176 rows): the host stops after
  * the sweep into spans (1.2 of the 5 ms a 32 x 32 grid's plan takes) and uploads those -- ~100 KB instead of the 14.7 MB
- * table; sq_fuse_plan_expand cuts them into items, finds the seam owners and orders the list with four kernels into the
+ * table; sq_fuse_plan_expand cuts them into items, finds the seam owners and orders the list with five small kernels into the
  * caller's table buffer (>= sq_fuse_plan_table_bytes) using a scratch buffer (>= sq_fuse_plan_expand_scratch_bytes, free
  * again on return), and waits for them.  The table is sq_fuse_plan_create's byte for byte.  Such a plan has no host copy
  * of its items: sq_fuse_plan_export / _upload refuse it, and sq_fuse_planes refuses it until it has been expanded.
