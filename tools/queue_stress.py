@@ -32,7 +32,7 @@ plan_ow = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_OVERWRITE)
 want_f32 = torch.from_numpy(np.stack([O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None, out_dtype=np.float32) for p in range(planes)])).to(dev)
 want_u16 = torch.from_numpy(np.stack([O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, None, out_dtype=np.uint16) for p in range(planes)]).astype(np.int32)).to(dev)
 want_ow = torch.from_numpy(np.stack([O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw) for p in range(planes)]).astype(np.int32)).to(dev)
-def run(name, pl, dtype, want, iters=600, sync_before=False, grid=0, flags=Q):
+def run(name, pl, dtype, want, iters=int(sys.argv[1]) if len(sys.argv) > 1 else 600, sync_before=False, grid=0, flags=Q):
     bad = 0
     for it in range(iters):
         a = native.empty_canvas(planes, ch, cw, dtype, dev)
