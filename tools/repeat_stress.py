@@ -103,3 +103,30 @@ for _ in range(max(20, REPS // 3)):
     torch.cuda.synchronize()
     bad += int(not (torch.equal(b.offsets, off0) and torch.equal(b.out[:int(b.offsets[-1])], out0)))
 report('Blosc chunk encoder, 24 chunks', bad, max(20, REPS // 3), t0)
+
+# --- flatfield estimate (BaSiC restatement: dozens of kernel launches per fit), min/max, feather plane groups with gains ---
+t0 = time.perf_counter()
+stack = torch.from_numpy((3000 + 800 * np.sin(np.add.outer(np.arange(512), np.arange(640)) / 97.0)[None] * (0.5 + rng.random((24, 1, 1)))
+                          + rng.integers(0, 200, (24, 512, 640))).astype(np.uint16)).to(dev)
+first, info0 = native.basic_fit(stack)
+first = first.clone()
+reps = max(10, REPS // 10)
+bad = 0
+for _ in range(reps):
+    out, info = native.basic_fit(stack)
+    bad += int(not (torch.equal(out, first) and info == info0))
+report(f'BaSiC flatfield fit of 24 tiles of 512x640 ({info0["reweight_iterations"]} reweightings, {info0["ladmap_iterations"]} inner iterations)', bad, reps, t0)
+t0 = time.perf_counter()
+first = native.tile_minmax(tiles).clone()
+bad = sum(int(not torch.equal(native.tile_minmax(tiles), first)) for _ in range(REPS))
+report('tile min / max of 12 tiles of 2048^2', bad, REPS, t0)
+t0 = time.perf_counter()
+planf = native.FusePlan(rects, th, th, hc, wc, native.SQ_FUSE_FEATHER)
+wantf = torch.from_numpy(np.stack([O.fuse_plane_feather(list(tl[p]), rects, hc, wc, flat, out_dtype=np.uint16) for p in range(planes)]).astype(np.int32)).to(dev)
+bad = 0
+for _ in range(REPS):
+    canvas = native.empty_canvas(planes, hc, wc, torch.uint16, dev)
+    canvas.view(torch.int16).fill_(-7)
+    native.fuse_planes(planf, d_tl, canvas, [d_flat] * planes, flags=native.SQ_FUSE_FORCE_QUEUES)
+    bad += int((canvas.to(torch.int32) != wantf).sum() > 0)
+report('feather fusion with gains, plane groups + queues, against the oracle', bad, REPS, t0)
