@@ -1454,9 +1454,15 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     // (measured on 312 x 3122 crops, lines of 6400 points: rows forward 2.87 -> see profiles/r03_kernel_probe_registration.log)
     auto line_threads = [&](int rl) {
         if (rl > 1) return 256;
-        return line_bytes >= 32 * 1024 ? 1024 : (line_bytes >= 16 * 1024 ? 512 : pick_threads(L.n1));
+        // (a 1024-point line on its own, 16 KB exactly: 256 threads = one radix-4 butterfly each per pass, 8.05 against
+        // 8.45 ms per 992-pair batch with 512, profiles/r03_exp_registration_threads.log)
+        return line_bytes >= 32 * 1024 ? 1024 : (line_bytes > 16 * 1024 ? 512 : pick_threads(L.n1));
     };
-    const int ntf = line_threads(rlf), nti = line_threads(rli);
+    int ntf = line_threads(rlf), nti = line_threads(rli);
+#ifdef SQ_EXPERIMENTS
+    if (const char *e = getenv("SQ_REG_FWD_THREADS")) ntf = std::max(64, std::min(1024, atoi(e)));
+    if (const char *e = getenv("SQ_REG_INV_THREADS")) nti = std::max(64, std::min(1024, atoi(e)));
+#endif
     const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
     // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
     const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
