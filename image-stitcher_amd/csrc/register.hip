@@ -693,14 +693,27 @@ __global__ __launch_bounds__(256) void minmax_kernel(const void *const *tile_ptr
 // ---------------------------------------------------------------------------------------------
 // K1: crop + normalise + two-for-one FFT along axis 1
 // ---------------------------------------------------------------------------------------------
+// v / range for the normalisation: both are integers in [0, 65535] (a pixel minus the tile's minimum, the tile's
+// maximum minus its minimum), and the quotient has to be numpy's float64 one bit for bit (its product with 65535 is
+// truncated to an integer).  The IEEE division is a dozen instructions, two of them quarter-rate, twice per pixel pair:
+// half of the forward row kernel's VALU work.  With the reciprocal of the range worked out once per thread, one
+// multiply and two fused multiply-adds (Markstein's correction) give the correctly rounded quotient on this domain --
+// not a theorem used on trust: sq_selftest_normalise_divide compares it with the compiler's division for ALL
+// 65536 x 65535 pairs (and range = 0: NaN either way) on the device, and the GPU tests run it.
+__device__ __forceinline__ double quotient_u16(double v, double range, double rinv) {
+    if (range == 0.0) return v / range;      // a constant tile (0 / 0 = NaN for its every pixel); x / 0 = inf as IEEE has it
+    const double q0 = v * rinv;
+    return fma(fma(-q0, range, v), rinv, q0);
+}
+
 template <typename T>
-__device__ __forceinline__ double normalised(const T *tile, int64_t idx, double lo, double range) {
+__device__ __forceinline__ double normalised(const T *tile, int64_t idx, double lo, double range, double rinv) {
     // ((img - min) / (max - min) * dtype_max).astype(dtype)   (stitcher.py:615-617)
     // range < 0 (a min > max entry in the table) means "already normalised": use the pixel as is
     if (range < 0.0) return (double)((uint32_t)tile[idx]);
     const double scale = sizeof(T) == 1 ? 255.0 : 65535.0;
     const double v = (double)((uint32_t)tile[idx]) - lo;   // exact: uint - uint, never negative
-    const double q = (v / range) * scale;                  // 0/0 -> NaN -> 0 below, as the x86 cast does
+    const double q = quotient_u16(v, range, rinv) * scale;  // 0/0 -> NaN -> 0 below, as the x86 cast does
     return q == q ? (double)(T)q : 0.0;
 }
 
@@ -731,12 +744,13 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
                                : static_cast<const T *>(P.tile_base) + pr.mov_tile * P.tile_stride;
     const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
     const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
+    const double rrinv = 1.0 / rrange, mrinv = 1.0 / mrange;      // once per thread (quotient_u16)
     Walk wi(tid, nt, n1);
     for (int e = tid; e < nrow * n1; e += nt, wi.next()) {
         const int l = wi.l, j = wi.j;
         const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
         const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
-        x[(int64_t)l * ld + put_pos(X, j)] = {normalised<T>(ref, rbase + j, rlo, rrange), normalised<T>(mov, mbase + j, mlo, mrange)};
+        x[(int64_t)l * ld + put_pos(X, j)] = {normalised<T>(ref, rbase + j, rlo, rrange, rrinv), normalised<T>(mov, mbase + j, mlo, mrange, mrinv)};
     }
     __syncthreads();
     lines_fft<false, false, GEN, true>(x, X, nrow, tid, nt);
@@ -1273,12 +1287,26 @@ __global__ __launch_bounds__(256) void normalize_kernel(const void *const *tile_
                                                         const uint32_t *minmax, T *out) {
     const int t = blockIdx.y;
     const T *tile = tile_ptrs ? static_cast<const T *>(tile_ptrs[t]) : static_cast<const T *>(tile_base) + t * tile_stride;
-    const double lo = minmax[2 * t], range = (double)minmax[2 * t + 1] - lo;
+    const double lo = minmax[2 * t], range = (double)minmax[2 * t + 1] - lo, rinv = 1.0 / range;
     const int64_t n = (int64_t)tile_h * tile_w;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / tile_w), x = (int)(i - (int64_t)y * tile_w);
-        out[(int64_t)t * n + i] = (T)normalised<T>(tile, (int64_t)y * pitch + x, lo, range);
+        out[(int64_t)t * n + i] = (T)normalised<T>(tile, (int64_t)y * pitch + x, lo, range, rinv);
     }
+}
+
+// every (v, range) the normalisation can meet, v and range in [0, 65535] (range 0: the quotient is NaN or inf either way):
+// quotient_u16 against the compiler's IEEE division, bit for bit
+__global__ __launch_bounds__(256) void selftest_normalise_kernel(unsigned long long *bad) {
+    const double range = (double)blockIdx.x, rinv = 1.0 / range;
+    unsigned long long local = 0;
+    for (int v = threadIdx.x; v < 65536; v += 256) {
+        const double a = (double)v / range, b = quotient_u16((double)v, range, rinv);
+        const bool same = __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+        local += same ? 0 : 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(bad, local);
 }
 
 int check_line(int n, const char *axis) {
@@ -1352,6 +1380,15 @@ extern "C" int sq_normalize_tiles(const void *const *tile_ptrs_dev, const void *
 }
 
 extern "C" int sq_register_line_supported(int32_t n) { return line_supported(n) ? 1 : 0; }
+
+extern "C" int sq_selftest_normalise_divide(uint64_t *mismatches_dev, void *stream_) {
+    if (!mismatches_dev) return fail(SQ_ERR_INVALID, "sq_selftest_normalise_divide: NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(selftest_normalise_kernel, dim3(65536), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(mismatches_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_selftest_normalise_divide: %s", hipGetErrorString(e));
+    return SQ_OK;
+}
 
 extern "C" int64_t sq_register_workspace_bytes(int32_t n_pairs, int32_t n0, int32_t n1, int32_t upsample_factor) {
     if (n_pairs < 0 || n0 < 2 || n1 < 2 || upsample_factor < 1 || upsample_factor > 100)

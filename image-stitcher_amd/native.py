@@ -21,7 +21,7 @@ SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
 SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS, SQ_FUSE_CONSECUTIVE_GROUPS = 1, 2, 4, 8, 16
-SQ_VERSION = 105
+SQ_VERSION = 106
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
                        ('dst_y', '<i4'), ('dst_x', '<i4')])
@@ -92,6 +92,7 @@ EXPORTS = {
     'sq_register_pairs': (C.c_int, [C.POINTER(_RegisterArgs), C.c_void_p]),
     'sq_selftest_flat_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_selftest_flat_divide_f64': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    'sq_selftest_normalise_divide': (C.c_int, [C.c_void_p, C.c_void_p]),
     'sq_selftest_blend_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
     'sq_blosc_chunk_count': (C.c_int64, [C.c_int32] * 5),
@@ -649,6 +650,15 @@ def selftest_flat_divide_f64(exponent: int, n_binades: int, negative: bool, seed
     out = torch.zeros(1, dtype=torch.int64, device=device)
     _check(lib().sq_selftest_flat_divide_f64(int(exponent), int(n_binades), int(bool(negative)), int(seed) & (2 ** 64 - 1),
                                              out.data_ptr(), _stream_ptr()), 'sq_selftest_flat_divide_f64')
+    return int(out.item())
+
+
+def selftest_normalise_divide(device) -> int:
+    """Mismatches between the registration kernels' shortened normalisation quotient and the IEEE float64 division over
+    every (numerator, range) pair of 16-bit integers (tests)."""
+    import torch
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    _check(lib().sq_selftest_normalise_divide(out.data_ptr(), _stream_ptr()), 'sq_selftest_normalise_divide')
     return int(out.item())
 
 

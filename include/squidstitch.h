@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 105 /* 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
+#define SQ_VERSION 106 /* 0.1.5: sq_selftest_normalise_divide; 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -289,6 +289,12 @@ int sq_selftest_flat_divide(int32_t exponent, int32_t n_binades, int32_t negativ
  * included) x all 65536 numerators; compares the quotient doubles and the clipped integers. */
 int sq_selftest_flat_divide_f64(int32_t exponent, int32_t n_binades, int32_t negative, uint64_t seed,
                                 uint64_t *mismatches_dev, void *stream);
+
+/* normalize_image's division (stitcher.py:615-617: (img - min) / (max - min) in float64) is computed in the registration
+ * kernels as a multiply by the reciprocal of the range plus Markstein's correction (two fused multiply-adds).  This
+ * compares that with the IEEE division, bit for bit, for ALL numerators 0..65535 x ALL ranges 0..65535 and ADDS the
+ * number of differing quotients to *mismatches_dev (zero it first; must stay 0). */
+int sq_selftest_normalise_divide(uint64_t *mismatches_dev, void *stream);
 
 /* The grouped feather blend divides the weighted sum of two quotients by the sum of their weights with the IEEE
  * sequence minus its range handling (the reciprocal of the weight sum is shared by the planes of a group).  This

@@ -223,3 +223,11 @@ def test_normalize_tiles_equals_reference_golden_and_oracle():
     got = native.normalize_tiles(torch.from_numpy(stack).to(_dev())).cpu().numpy()
     for i in range(5):
         np.testing.assert_array_equal(got[i], O.normalize_image(stack[i], np.uint16))
+
+
+def test_normalisation_quotient_equals_ieee_division_exhaustively():
+    """K1 and sq_normalize_tiles compute (pixel - min) / (max - min) as a multiply by the reciprocal of the range plus
+    Markstein's correction; on the device, for ALL 65536 x 65536 (numerator, range) pairs of 16-bit integers, the result
+    is the IEEE float64 quotient bit for bit (NaN for 0 / 0 either way)."""
+    import torch
+    assert native.selftest_normalise_divide(torch.device('cuda:0')) == 0
