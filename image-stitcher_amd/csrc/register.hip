@@ -707,15 +707,22 @@ __device__ __forceinline__ double quotient_u16(double v, double range, double ri
 }
 
 template <typename T>
-__device__ __forceinline__ double normalised(const T *tile, int64_t idx, double lo, double range, double rinv) {
+__device__ __forceinline__ double normalised_px(uint32_t px, double lo, double range, double rinv) {
     // ((img - min) / (max - min) * dtype_max).astype(dtype)   (stitcher.py:615-617)
     // range < 0 (a min > max entry in the table) means "already normalised": use the pixel as is
-    if (range < 0.0) return (double)((uint32_t)tile[idx]);
+    if (range < 0.0) return (double)px;
     const double scale = sizeof(T) == 1 ? 255.0 : 65535.0;
-    const double v = (double)((uint32_t)tile[idx]) - lo;   // exact: uint - uint, never negative
+    const double v = (double)px - lo;                       // exact: uint - uint, never negative
     const double q = quotient_u16(v, range, rinv) * scale;  // 0/0 -> NaN -> 0 below, as the x86 cast does
     return q == q ? (double)(T)q : 0.0;
 }
+template <typename T>
+__device__ __forceinline__ double normalised(const T *tile, int64_t idx, double lo, double range, double rinv) {
+    return normalised_px<T>((uint32_t)tile[idx], lo, range, rinv);
+}
+struct __attribute__((packed)) PixVec16 {   // 16 bytes of pixels at any alignment
+    uint32_t w[4];
+};
 
 // One block = P.rl consecutive rows of one pair (as many as fit 64 KB of LDS, at most 8), sent through
 // the line FFT together: one barrier per pass for the batch, and eight times fewer, fuller blocks
@@ -745,12 +752,32 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
     const double rlo = P.minmax[2 * pr.ref_tile], rrange = (double)P.minmax[2 * pr.ref_tile + 1] - rlo;
     const double mlo = P.minmax[2 * pr.mov_tile], mrange = (double)P.minmax[2 * pr.mov_tile + 1] - mlo;
     const double rrinv = 1.0 / rrange, mrinv = 1.0 / mrange;      // once per thread (quotient_u16)
-    Walk wi(tid, nt, n1);
-    for (int e = tid; e < nrow * n1; e += nt, wi.next()) {
-        const int l = wi.l, j = wi.j;
-        const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
-        const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
-        x[(int64_t)l * ld + put_pos(X, j)] = {normalised<T>(ref, rbase + j, rlo, rrange, rrinv), normalised<T>(mov, mbase + j, mlo, mrange, mrinv)};
+    // uint16 tiles: 8 pixels (16 bytes, any alignment) per lane and load instead of one -- a crop row is a run of
+    // consecutive pixels; the pixels after the last whole group of 8, and uint8 tiles, one at a time
+    const int g8 = sizeof(T) == 2 ? n1 >> 3 : 0;
+    if (g8) {
+        Walk wg(tid, nt, g8);
+        for (int e = tid; e < nrow * g8; e += nt, wg.next()) {
+            const int l = wg.l, j0 = wg.j << 3;
+            const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0 + j0;
+            const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0 + j0;
+            const PixVec16 rv = *reinterpret_cast<const PixVec16 *>(ref + rbase), mv = *reinterpret_cast<const PixVec16 *>(mov + mbase);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t rp = (rv.w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, mp = (mv.w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                x[(int64_t)l * ld + put_pos(X, j0 + k)] = {normalised_px<T>(rp, rlo, rrange, rrinv), normalised_px<T>(mp, mlo, mrange, mrinv)};
+            }
+        }
+    }
+    const int rest0 = g8 << 3, nrest = n1 - rest0;
+    if (nrest) {
+        Walk wi(tid, nt, nrest);
+        for (int e = tid; e < nrow * nrest; e += nt, wi.next()) {
+            const int l = wi.l, j = rest0 + wi.j;
+            const int64_t rbase = (int64_t)(pr.ref_y0 + r0 + l) * P.tile_pitch + pr.ref_x0;
+            const int64_t mbase = (int64_t)(pr.mov_y0 + r0 + l) * P.tile_pitch + pr.mov_x0;
+            x[(int64_t)l * ld + put_pos(X, j)] = {normalised<T>(ref, rbase + j, rlo, rrange, rrinv), normalised<T>(mov, mbase + j, mlo, mrange, mrinv)};
+        }
     }
     __syncthreads();
     lines_fft<false, false, GEN, true>(x, X, nrow, tid, nt);
