@@ -149,7 +149,11 @@ def main():
         out = run_region(ctx)
         if world == 1 and args.workload is None and not args.planes and args.traffic_bytes is None and not args.no_live_traffic:
             torch.cuda.empty_cache()          # the passes are child processes of their own: they need the HBM this one held
-            live = live_traffic(n_planes=wl['channels'] * wl['nz'])
+            try:
+                live = live_traffic(n_planes=wl['channels'] * wl['nz'])
+            except Exception as exc:      # whatever goes wrong around the profiler must not cost the line its other numbers
+                print(f'[bench] live traffic: {type(exc).__name__}: {exc}; keeping the committed measurement', file=sys.stderr)
+                live = None
             if live is not None:
                 out['roofline']['traffic'], out['roofline']['traffic_source'] = live
     if rank == 0:
