@@ -187,15 +187,28 @@ def live_traffic(n_planes, timeout_s=120):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             out_dir = os.path.join(tmp, counter)
             cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '-o', 'run', '--'] + child
+            # the pass runs in a process group of its own: if it overruns, the profiler AND the program under it are ended
+            # (this exact group, nothing else), so that no copy of the bench keeps the GPU's memory
             try:
-                done = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-            except (OSError, subprocess.TimeoutExpired) as exc:
-                print(f'[bench] live traffic: {counter} pass did not finish ({exc}); keeping the committed measurement', file=sys.stderr)
+                proc = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            except OSError as exc:
+                print(f'[bench] live traffic: cannot start the {counter} pass ({exc}); keeping the committed measurement', file=sys.stderr)
+                return None
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                print(f'[bench] live traffic: {counter} pass did not finish in {timeout_s} s; keeping the committed measurement', file=sys.stderr)
                 return None
             files = glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True)
-            if done.returncode != 0 or not files:
-                print(f'[bench] live traffic: {counter} pass failed (rc {done.returncode}); keeping the committed measurement: '
-                      f'{done.stderr.decode(errors="replace")[-300:]}', file=sys.stderr)
+            if proc.returncode != 0 or not files:
+                print(f'[bench] live traffic: {counter} pass failed (rc {proc.returncode}); keeping the committed measurement: '
+                      f'{err.decode(errors="replace")[-300:]}', file=sys.stderr)
                 return None
             with open(files[0]) as fh:
                 vals = [float(r['Counter_Value']) for r in csv.DictReader(fh)

@@ -358,3 +358,46 @@ with open(os.path.join(d, 'run_counter_collection.csv'), 'w') as fh:
     # a failing pass leaves the caller with the committed measurement
     fake.write_text('#!/bin/sh\nexit 7\n')
     assert bench.live_traffic(n_planes=40) is None
+
+
+def test_bench_live_traffic_ends_an_overrunning_pass_with_its_children(monkeypatch, tmp_path):
+    """A PMC pass that overruns its time is ended as a process GROUP (profiler + the program under it), so no copy of
+    the bench is left holding the GPU; the caller keeps the committed measurement."""
+    import importlib.util
+    import stat
+    import time
+    spec = importlib.util.spec_from_file_location('bench_for_test3', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pidfile = tmp_path / 'grandchild.pid'
+    fake = tmp_path / 'bin' / 'rocprofv3'
+    fake.parent.mkdir()
+    fake.write_text(f'''#!/usr/bin/env python3
+import subprocess, sys, time
+child = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])
+open({str(pidfile)!r}, 'w').write(str(child.pid))
+time.sleep(60)
+''')
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv('PATH', str(fake.parent) + os.pathsep + os.environ['PATH'])
+    for k in [k for k in os.environ if k.startswith(('ROCPROF', 'ROCP_'))] + ['SQ_BENCH_PMC_CHILD']:
+        monkeypatch.delenv(k, raising=False)
+    t0 = time.perf_counter()
+    assert bench.live_traffic(n_planes=40, timeout_s=2) is None
+    assert time.perf_counter() - t0 < 20
+    pid = int(pidfile.read_text())
+    for _ in range(50):          # the group has been sent SIGKILL: the grandchild goes within moments
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        # a zombie still answers kill(0) until it is reaped by init: look at its state instead
+        try:
+            with open(f'/proc/{pid}/stat') as fh:
+                if fh.read().split()[2] == 'Z':
+                    break
+        except FileNotFoundError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError('the program under the profiler survived the end of the pass')
