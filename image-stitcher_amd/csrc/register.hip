@@ -1191,7 +1191,11 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TB; ++j) acc[i][j] = {0.0, 0.0};
-        for (int kc = 0; kc < n1h; kc += UR_KC) {
+        // a power-of-two n1 has n1h = n1 / 2 + 1 columns: one more than a whole number of chunks.  One or two columns left
+        // over are not worth a chunk of their own (staging, two barriers, UR_KC steps of which one does anything: a ninth
+        // chunk for the 129 columns of a 256-wide crop): each thread adds them from global memory after the loop
+        const int left = n1h % UR_KC, kfull = left <= 2 ? n1h - left : n1h;
+        for (int kc = 0; kc < kfull; kc += UR_KC) {
             for (int e = tid; e < 2 * ROWS * UR_KC; e += 256) {
                 const int m = e / (ROWS * UR_KC), ik = e - m * (ROWS * UR_KC);
                 const int i = ik / UR_KC, k = ik - i * UR_KC;
@@ -1226,6 +1230,24 @@ __global__ __launch_bounds__(256) void upsample_rows_kernel(RegParams P) {
             __syncthreads();
         }
         const int k0 = row0 + rt;
+        for (int k1 = kfull; k1 < n1h; ++k1) {      // the left-over columns (same order of accumulation: ascending k1)
+            if (k0 >= n_slots) break;
+            const int km1 = k0 ? n0 - k0 : nyquist;
+            const cplx p = Pm[(int64_t)k0 * sp + k1], q = km1 >= 0 ? Pm[(int64_t)km1 * sp + k1] : cplx{0.0, 0.0};
+            const cplx pm = cconj(self ? p : q), qm = cconj(self ? q : p);
+            const bool mirrored = k1 >= 1 && k1 <= n_mirror;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = b0 + TB * bt + j;
+                cplx w = {0.0, 0.0}, wm = {0.0, 0.0};
+                if (b < R) {
+                    w = E[posmod((long long)(b - off1) * signed_freq(k1, n1), M)];
+                    if (mirrored) wm = E[posmod((long long)(b - off1) * signed_freq(n1 - k1, n1), M)];
+                }
+                acc[0][j] = cfma(pm, wm, cfma(p, w, acc[0][j]));
+                acc[1][j] = cfma(qm, wm, cfma(q, w, acc[1][j]));
+            }
+        }
         if (k0 < n_slots) {
             const int km = k0 ? n0 - k0 : nyquist;
 #pragma unroll
