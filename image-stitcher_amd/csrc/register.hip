@@ -299,7 +299,7 @@ __device__ __forceinline__ cplx twiddle(const cplx *__restrict__ tw, int idx) {
 // (The half twiddle table copied into LDS per block -- ds_read instead of L1-cached global loads -- was built and
 // measured in round 3: 1 984 pairs of 1024 x 256 in 33.3 instead of 30.0 ms, 42-44 k instead of 46-50 k pairs/s in
 // 30-pair batches.  The table is L1-resident; the LDS copy only costs occupancy and LDS bandwidth.  Not kept.)
-template <bool INV, bool PRE = false>
+template <bool INV, bool PRE = false, bool PREFETCH = true>
 __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__restrict__ tw, int tid, int nt) {
     const int logn = 31 - __clz(n);
     if (!PRE) {      // (PRE: the caller stored the line bit-reversed already, put_pos)
@@ -327,11 +327,31 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
         __syncthreads();
         s = 2;
     }
-    const int quads = n >> 2;
+    const int quads = n >> 2, total = nlines * quads;
+    // A pass is short -- one or two butterflies per thread when a block holds a line or two -- and the table read of its
+    // twiddle sits right on its critical path (an L1 / L2 round trip before the first product).  The twiddles of the NEXT
+    // pass depend on nothing but the butterfly's index, so this pass issues their reads before it touches its own data:
+    // they arrive while the pass runs and the barrier is waited for.  (The first PF butterflies of a thread; a thread
+    // with more of them reads the others' twiddles when it gets there, as before.  PREFETCH = false: the instantiations
+    // inside the general (mixed-radix) kernels, which sit at their register limit -- 8 more doubles cost them a wave:
+    // 312 x 3122 crops 7.2 -> 6.3 k pairs/s.)
+    constexpr int PF = PREFETCH ? 2 : 0;
+    cplx wcur[PF ? PF : 1], wnxt[PF ? PF : 1];
+    bool primed = false;
+    auto twiddle_of = [&](int s_, int e) {      // w2 of butterfly e in the pass that fuses stages s_ and s_ + 1
+        const int q = e & (quads - 1), k = q & ((1 << (s_ - 1)) - 1);
+        return twiddle<INV>(tw, k * (n >> (s_ + 1)));
+    };
     for (; s < logn; s += 2) {
         const int half = 1 << (s - 1);
         const int ts2 = n >> (s + 1);      // (ts1 = n >> s = 2 ts2 is the stride of the stage-s twiddle)
-        for (int e = tid; e < nlines * quads; e += nt) {
+        const bool more = s + 2 < logn;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (tid + i * nt < total) wnxt[i] = twiddle_of(s + 2, tid + i * nt);
+        }
+        auto butterfly4 = [&](int e, cplx w2pre, bool have) {
             const int l = e >> (logn - 2), q = e & (quads - 1);
             const int k = q & (half - 1);
             cplx *x = base + (int64_t)l * n + (((q >> (s - 1)) << (s + 1)) + k);
@@ -345,7 +365,7 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
                 u2 = a2;
                 u3 = rot90<INV>(a3);
             } else {
-                const cplx w2 = twiddle<INV>(tw, k * ts2), w3 = rot90<INV>(w2), w1 = cmul(w2, w2);
+                const cplx w2 = have ? w2pre : twiddle<INV>(tw, k * ts2), w3 = rot90<INV>(w2), w1 = cmul(w2, w2);
                 // stage s: (x0, x1) and (x2, x3), both with w1
                 const cplx t1 = cmul(w1, x1), t3 = cmul(w1, x3);
                 a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
@@ -356,8 +376,21 @@ __device__ void lines_fft_pow2(cplx *base, int n, int nlines, const cplx *__rest
             x[2 * half] = csub(a0, u2);
             x[half] = cadd(a1, u3);
             x[3 * half] = csub(a1, u3);
-        }
+        };
+        int e = tid;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if (e < total) {
+                butterfly4(e, wcur[i], primed);
+                e += nt;
+            }
+        for (; e < total; e += nt) butterfly4(e, cplx{0.0, 0.0}, false);
         __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) wcur[i] = wnxt[i];
+            primed = true;
+        }
     }
 }
 
@@ -475,7 +508,7 @@ __device__ void lines_fft_mixed(cplx *base, int N, int nlines, const cplx *__res
 template <bool INV, bool BWD, bool GEN, bool PRE = false>
 __device__ __forceinline__ void lines_fft_plan(cplx *base, int nlines, const cplx *__restrict__ tw, const AxisPlan &pl, int tid, int nt) {
     if (GEN && pl.nf) lines_fft_mixed<INV, !BWD>(base, pl.len, nlines, tw, pl, tid, nt);
-    else lines_fft_pow2<INV, PRE>(base, pl.len, nlines, tw, tid, nt);
+    else lines_fft_pow2<INV, PRE, !GEN>(base, pl.len, nlines, tw, tid, nt);
 }
 
 // Any other length n (a prime factor above 13): Bluestein's chirp-z form of the same DFT, in place in a line of
