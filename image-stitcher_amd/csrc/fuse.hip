@@ -1401,7 +1401,10 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
         t0[z] = sgpr(static_cast<const T *>(A.tile[zz]));
         t1[z] = sgpr(static_cast<const T *>(A.ltile[zz]));
     }
-    const float *flat = FLAT ? static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
+    // FLAT = 2: float64 gains, which feather mode takes as float32 (the per-plane blend casts every gain it loads: the
+    // arithmetic is float32 in either case) -- loaded as doubles here, cast once per 8-pixel group
+    typedef typename std::conditional<FLAT == 2, double, float>::type GM;
+    const GM *flat = FLAT ? static_cast<const GM *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
     const int ya = sgpr(A.first.b), xa = sgpr(A.first.c), yb = sgpr(A.seam.b), xb = sgpr(A.seam.c);
     const int G = n / VEC + 1;   // upper bound of the whole groups of a row
     for (int idx = tid; idx < rows * G; idx += 256) {
@@ -1415,9 +1418,18 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
         const int y0 = ya + r, x0 = xa + p0, y1 = yb + r, x1 = xb + p0;
         const int64_t s0 = (int64_t)y0 * P.tile_pitch + x0, s1 = (int64_t)y1 * P.tile_pitch + x1;
         f32x4 ga0{}, ga1{}, gb0{}, gb1{};
-        if (FLAT) {
+        if constexpr (FLAT == 1) {
             const float *gp0 = flat + (int64_t)y0 * P.tile_w + x0, *gp1 = flat + (int64_t)y1 * P.tile_w + x1;
             ga0 = ldg<F32x4U>(gp0), ga1 = ldg<F32x4U>(gp0 + 4), gb0 = ldg<F32x4U>(gp1), gb1 = ldg<F32x4U>(gp1 + 4);
+        } else if constexpr (FLAT == 2) {
+            const double *gp0 = flat + (int64_t)y0 * P.tile_w + x0, *gp1 = flat + (int64_t)y1 * P.tile_w + x1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f64x2 a0 = ldg<F64x2U>(gp0 + 2 * h), a1 = ldg<F64x2U>(gp0 + 4 + 2 * h);
+                const f64x2 b0 = ldg<F64x2U>(gp1 + 2 * h), b1 = ldg<F64x2U>(gp1 + 4 + 2 * h);
+                ga0[2 * h] = (float)a0[0], ga0[2 * h + 1] = (float)a0[1], ga1[2 * h] = (float)a1[0], ga1[2 * h + 1] = (float)a1[1];
+                gb0[2 * h] = (float)b0[0], gb0[2 * h + 1] = (float)b0[1], gb1[2 * h] = (float)b1[0], gb1[2 * h + 1] = (float)b1[1];
+            }
         }
         u32x4 ra[ZB], rb[ZB];
 #pragma unroll
@@ -1493,7 +1505,7 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
         }
         if (p < 0) continue;
         const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
-        const float ga = FLAT ? ldg_s<float>(flat + (int64_t)y0 * P.tile_w + x0) : 1.0f, gb = FLAT ? ldg_s<float>(flat + (int64_t)y1 * P.tile_w + x1) : 1.0f;
+        const float ga = FLAT ? (float)ldg_s<GM>(flat + (int64_t)y0 * P.tile_w + x0) : 1.0f, gb = FLAT ? (float)ldg_s<GM>(flat + (int64_t)y1 * P.tile_w + x1) : 1.0f;
         const float fa = FLAT ? recip_for<1>(ga) : 1.0f, fb = FLAT ? recip_for<1>(gb) : 1.0f;
         const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
         const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
@@ -1552,16 +1564,18 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
         const int gn = sgpr(A.g.n);
         if (gn == 1) {
             feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
-        } else if (F32OUT && it.nref <= 1) {
-            // float32 canvas: nothing of a one-tile (or empty) item is shared between the planes but the geometry --
-            // the per-plane path (float(v) or v / g stored as it is), plane after plane
+        } else if ((F32OUT || FLAT == 2) && it.nref <= 1) {
+            // float32 canvas, or float64 gains: nothing of a one-tile (or empty) item is shared between the planes but the
+            // geometry (and gains that the grouped one-tile path does not take as doubles) -- the per-plane path, plane after plane
             for (int z = 0; z < gn; ++z) feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[z]), it, wave, lane);
         } else if (it.nref <= 1) {
             Item one = it;
             one.a = sgpr(A.first.a);
             one.b = sgpr(A.first.b);
             one.c = sgpr(A.first.c);
-            if (!FLAT) {   // nothing to share: the plain pipelined copy, plane after plane
+            if constexpr (FLAT == 2) {
+                // (taken by the branch above)
+            } else if (!FLAT) {   // nothing to share: the plain pipelined copy, plane after plane
                 for (int z = 0; z < gn; ++z)
                     process_item<T, 0, 1>(P, sgpr(A.g.plane[z]), one, sgpr(static_cast<const T *>(A.tile[z])), wave, lane);
             } else if (gn == ZB) {
@@ -1997,7 +2011,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (flat == 1) SQ_FEATHER_F(T, O, 1); \
         SQ_FEATHER_F(T, O, 2);           \
     } while (0)
-    if (u16 && flat != 2 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS) &&
+    if (u16 && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS) &&
         std::min(a->tile_h, a->tile_w) <= BLEND_WSUM_MAX) {   // a weight is at most half the shorter tile side, a weight sum twice that
         // planes that share a gain image (every gain moderate), or that have none, go through the items together
         // (fuse_feather_zg_kernel)
@@ -2015,9 +2029,11 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         return launch_zg(fuse_feather_zg_kernel<F, false, O>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                \
     } while (0)
         if (f32out) {      // float32 canvas: the blended strips through the grouped blend, one-tile items plane after plane
+            if (flat == 2) SQ_FEATHER_ZG(2, float);
             if (flat == 1) SQ_FEATHER_ZG(1, float);
             SQ_FEATHER_ZG(0, float);
         }
+        if (flat == 2) SQ_FEATHER_ZG(2, uint16_t);      // float64 gains: likewise (the blend takes them as float32)
         if (flat == 1) SQ_FEATHER_ZG(1, uint16_t);
         SQ_FEATHER_ZG(0, uint16_t);
 #undef SQ_FEATHER_ZG

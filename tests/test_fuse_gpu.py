@@ -538,6 +538,54 @@ def test_seam_lines_have_one_writer(seed, queues, gdtype):
 
 @pytest.mark.parametrize('seed', range(4))
 @pytest.mark.parametrize('queues', [False, True])
+def test_feather_plane_groups_with_float64_gains(seed, queues):
+    """Feather mode with float64 gain images through the plane groups (round 3): the blend takes a gain as float32 (the
+    per-plane kernel casts every gain it loads), so the grouped blend loads the doubles and casts once per 8-pixel group.
+    uint16 canvas on even seeds, float32 on odd ones; against the oracle and the per-plane kernel."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(6200 + seed)
+    th, tw = int(rng.integers(20, 70)), int(rng.integers(40, 260))
+    rows, cols = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+    oy, ox = int(rng.integers(2, th // 3)), int(rng.integers(2, tw // 3))
+    n = rows * cols
+    rects = np.zeros((n, 6), dtype=np.int64)
+    for r in range(rows):
+        for c in range(cols):
+            rects[r * cols + c] = (0, 0, th, tw, r * (th - oy) + c * 2, c * (tw - ox) + (rows - 1 - r) * 3)
+    ch = int(rects[:, 4].max() + th + rng.integers(0, 9))
+    cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
+    planes = int(rng.integers(2, 13))
+    tiles = rng.integers(0, 65536, size=(planes, n, th, tw)).astype(np.uint16)
+    gains = [np.exp(rng.normal(0, 0.4, size=(th, tw))).astype(np.float64) for _ in range(3)]
+    gains[1][rng.integers(0, th), rng.integers(0, tw)] = 2.0 ** -30      # not moderate: groups of one for its planes
+    which = [int(rng.integers(0, 3)) for _ in range(planes)]
+    if planes >= 7:
+        which[:6] = [0] * 6
+    d_gains = [torch.from_numpy(g).to(dev) for g in gains]
+    flats = [d_gains[k] for k in which]
+    out_np = np.float32 if seed % 2 else np.uint16
+    out_t = torch.float32 if seed % 2 else torch.uint16
+    plan = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_FEATHER)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    grouped = native.empty_canvas(planes, ch, cw, out_t, dev)
+    single = native.empty_canvas(planes, ch, cw, out_t, dev)
+    for c in (grouped, single):
+        c.view(torch.int16 if out_t == torch.uint16 else torch.float32).fill_(-7)
+    native.fuse_planes(plan, d_tiles, grouped, flats, flags=flags)
+    native.fuse_planes(plan, d_tiles, single, flats, flags=flags | native.SQ_FUSE_NO_PLANE_GROUPS)
+    torch.cuda.synchronize()
+    for p in range(planes):
+        want = O.fuse_plane_feather(list(tiles[p]), rects, ch, cw, gains[which[p]], out_dtype=out_np)
+        for name, got in (('plane groups', grouped[p].cpu().numpy()), ('per-plane kernel', single[p].cpu().numpy())):
+            ys, xs = np.nonzero(got != want)
+            assert not len(ys), (f'{name}, plane {p} (gain image {which[p]}) of {planes}: {len(ys)} voxels differ, first '
+                                 f'{[(int(y), int(x), float(got[y, x]), float(want[y, x])) for y, x in list(zip(ys, xs))[:10]]}')
+
+
+@pytest.mark.parametrize('seed', range(4))
+@pytest.mark.parametrize('queues', [False, True])
 def test_feather_plane_groups_with_a_float32_canvas(seed, queues):
     """Feather mode into a float32 canvas with plane groups (round 3): the blended strips of the planes that share a
     gain image go through the grouped blend (blend_item_zg<.., float>), one-tile items plane after plane.  1..12 planes
