@@ -23,11 +23,14 @@ reference's two centre pairs on rank 0 and an 8-int32 row instead).  A rank walk
 (tiles + canvases of a batch fill the card); a batch's tiles are synthesised on the device BEFORE that batch's launch,
 outside its event pair (inputs resident when timing starts, as the contract says; the generator is not part of the
 hot path).  One step = the whole 200-plane job; the timed seconds of a rank are registration + all-gather + plan
-(built and uploaded inside the first timed job, re-used while the shifts stay) + the fusion launches of all its
-batches, and the job time is the MAX over ranks.  ``--workload cfg4`` runs the same job on one GPU.
+(built inside the first timed job -- host sweep into spans, work list expanded on the device -- and re-used while the
+shifts stay) + the fusion launches of all its batches, and the job time is the MAX over ranks.  ``--workload cfg4``
+runs the same job on one GPU.
 
 Printed JSON (rank 0, one line): whole-job Mvoxel/s, plus
-  roofline     fusion kernel, algorithmic bytes / HIP-event launch time vs 8 TB/s HBM peak (rank 0's launches)
+  roofline     fusion kernel, algorithmic bytes / HIP-event launch time vs 8 TB/s HBM peak (rank 0's launches);
+               traffic = HBM bytes per launch from the PMC counters: at N = 1 measured by this run itself (two child passes
+               under rocprofv3 --pmc after the timed region, live_traffic), else the last committed measurement, labelled
   cpu_baseline the numpy oracle (oracle/stitch_oracle.py) timed on this box's host on a bounded sample of
                the same workload (N = 1, rank 0 only), and the genuine reference's timing from the authoring
                container for the record
