@@ -173,11 +173,14 @@ __global__ __launch_bounds__(EXPAND_THREADS) void bucket_scan_kernel(ExpandParam
     if (tid == EXPAND_THREADS - 1) P.tables[k] = part[tid];      // count[k]
 }
 
-__global__ void bucket_tables_kernel(ExpandParams P) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {      // a few hundred buckets: one thread, plan.cpp's arithmetic line by line
-        const int nblk = P.nblk;
-        const int64_t *count = P.tables;
-        int64_t *start = P.tables + nblk, *lane_base = start + nblk + 1, *tail_at = lane_base + nblk, *common_out = tail_at + NX;
+// a few hundred buckets: one thread, plan.cpp's arithmetic line by line -- on copies in LDS (the same loops straight on
+// global memory took 54 us: a chain of dependent round trips)
+__global__ __launch_bounds__(EXPAND_THREADS) void bucket_tables_kernel(ExpandParams P) {
+    __shared__ int64_t count[MAX_BUCKETS], start[MAX_BUCKETS + 1], lane_base[MAX_BUCKETS], tail_at[NX + 1];
+    const int nblk = P.nblk, tid = threadIdx.x;
+    for (int b = tid; b < nblk; b += EXPAND_THREADS) count[b] = P.tables[b];
+    __syncthreads();
+    if (tid == 0) {
         start[0] = 0;
         for (int b = 0; b < nblk; ++b) start[b + 1] = start[b] + count[b];
         int64_t lane_len[NX] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -193,9 +196,14 @@ __global__ void bucket_tables_kernel(ExpandParams P) {
             tail_at[x] = tail;
             tail += lane_len[x] - common;
         }
-        *common_out = common;
+        tail_at[NX] = common;
         P.header_dev->lane_items = common;
     }
+    __syncthreads();
+    int64_t *g_start = P.tables + nblk, *g_lane_base = g_start + nblk + 1, *g_tail_at = g_lane_base + nblk;   // tail_at[NX] = common
+    for (int b = tid; b <= nblk; b += EXPAND_THREADS) g_start[b] = start[b];
+    for (int b = tid; b < nblk; b += EXPAND_THREADS) g_lane_base[b] = lane_base[b];
+    for (int x = tid; x <= NX; x += EXPAND_THREADS) g_tail_at[x] = tail_at[x];
 }
 
 __global__ __launch_bounds__(EXPAND_THREADS) void place_items_kernel(ExpandParams P) {
@@ -323,7 +331,7 @@ extern "C" int sq_fuse_plan_expand(sq_fuse_plan *plan, void *table_dev, int64_t 
             hipLaunchKernelGGL(expand_items_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
             hipLaunchKernelGGL(seam_owners_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
             hipLaunchKernelGGL(bucket_scan_kernel, dim3(S.nblk), dim3(EXPAND_THREADS), 0, stream, P);
-            hipLaunchKernelGGL(bucket_tables_kernel, dim3(1), dim3(64), 0, stream, P);
+            hipLaunchKernelGGL(bucket_tables_kernel, dim3(1), dim3(EXPAND_THREADS), 0, stream, P);
             hipLaunchKernelGGL(place_items_kernel, dim3(S.n_blocks), dim3(EXPAND_THREADS), 0, stream, P);
             e = hipGetLastError();
             // the one number the host needs back: how much of the list is lane-interleaved (sq_fuse_planes reads it from
