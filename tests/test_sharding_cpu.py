@@ -401,3 +401,18 @@ time.sleep(60)
         time.sleep(0.1)
     else:
         raise AssertionError('the program under the profiler survived the end of the pass')
+
+
+def test_bench_committed_traffic_scales_with_the_planes_per_launch():
+    """N > 1 lines carry the committed PMC measurement of a 10-plane launch of the headline geometry; a rank whose mean
+    launch holds fewer planes (25 planes = 10 + 10 + 5) gets it scaled, and says so; unknown workloads get None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_test4', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full, src = bench.committed_traffic('cfg4', 10)
+    assert full and 'not measured in this run' in src and 'scaled' not in src
+    part, src2 = bench.committed_traffic('cfg4', 25 / 3)
+    assert abs(part - full * (25 / 3) / 10) < 1 and 'scaled to the 8.33333 planes' in src2
+    assert bench.committed_traffic('cfg2', 1)[0] is None
+    assert bench.committed_traffic('cfg3', 40)[0] > 1.5e11
