@@ -85,9 +85,11 @@ def main():
                     help="region workloads: where a (c, z) plane's canvas sits in the canvas allocation.  'spread' (default): "
                          "z-major, so that the z planes of a channel -- which go through the kernel together -- lie a channel "
                          "count of planes apart, spread over the whole allocation; 'plane': plane p = c * Z + z at slot p")
-    ap.add_argument('--layout', choices=['arena', 'separate'], default='arena',
-                    help="'arena' (default): canvas slots and tile stacks interleaved in ONE allocation, so that the canvas planes "
-                         "are spread over all the memory the job holds; 'separate': one allocation each (round 2)")
+    ap.add_argument('--layout', choices=['mixed', 'arena', 'separate'], default='mixed',
+                    help="'mixed' (default): the canvas in a native.DeviceArena -- physical slices classified by a probe and mapped "
+                         "round-robin over the card's three memory classes (csrc/arena.hip), tiles in a plain allocation: what "
+                         "Stitcher.stitch_region does; 'arena': canvas slots and tile stacks interleaved in ONE plain allocation "
+                         "(round 3); 'separate': one plain allocation each (round 2)")
     ap.add_argument('--registration-stream', choices=['side', 'main'], default='main',
                     help="region workloads: the next region's centre-pair registration on the launch stream ahead of the fusion "
                          "launch (default), or on a stream of its own beside the launch in flight (measured: the 0.3 ms it saves "
@@ -123,6 +125,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    check_device_count(world, torch.cuda.device_count())
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
@@ -260,6 +263,41 @@ def launch_ranks(n, bench_args):
 # ------------------------------------------------------------------------------------------------------------
 # shared pieces
 # ------------------------------------------------------------------------------------------------------------
+def check_device_count(world, n_devices):
+    """One process per GPU: a world of N ranks needs N devices on this node (SQ_DIST_BACKEND=gloo rehearses N ranks on
+    fewer cards and says so itself)."""
+    if n_devices < world and os.environ.get('SQ_DIST_BACKEND', 'nccl') == 'nccl':
+        raise SystemExit(f"bench.py --gpus {world}: this node shows {n_devices} GPU(s) to torch.cuda.device_count(); one rank per GPU "
+                         f"needs {world} (rehearse with SQ_DIST_BACKEND=gloo on fewer cards)")
+
+
+def parallelism_text(world, backend, all_pairs):
+    """config.parallelism of the headline job, for the registration mode that actually ran."""
+    coll = 'RCCL' if backend == 'nccl' else backend
+    head = f"planes dealt over {world} GPU{'s' if world != 1 else ''} in contiguous runs (a channel's z planes stay together)"
+    if all_pairs:
+        return (f"{head}; registration pairs dealt over the ranks in contiguous runs of the tile-row-ordered pair list, every rank "
+                f"registers its run, [n_pairs, 3] float64 pair table all-gathered over {coll}, per-axis median on every rank; "
+                "no image data exchanged")
+    return f"{head}; rank 0 registers the reference's centre pairs, 8-int32 shift row all-gathered over {coll}; no image data exchanged"
+
+
+def with_scale_keys(out, job):
+    """Every bench line carries the point of the strong-scaling curve under ONE key pair, whatever its own `value` measures:
+    `scale_workload` / `scale_value` = the headline job (BASELINE configs[3], 200 planes of the 32x32 grid) on this run's GPUs.
+    A job line is that point itself; the N = 1 region line (value = config 3, the largest resident configuration) takes it
+    from the job it runs afterwards on the same GPU (`headline_job_on_this_gpu`); a line without such a job says null."""
+    if job is None:
+        out['scale_workload'], out['scale_value'], out['scale_unit'] = None, None, out.get('unit')
+        out['scale_note'] = 'no headline job in this run (a --workload / --planes override, or SQ_BENCH_NO_REFERENCE_JOB)'
+    else:
+        out['scale_workload'], out['scale_value'], out['scale_unit'] = job['workload'], job['value'], job['unit']
+        out['scale_ms_per_job'], out['scale_wall_ms_per_job'] = job.get('ms_per_step'), job.get('wall_ms_per_job')
+        out['scale_note'] = ('the strong-scaling curve is drawn from scale_value at every N (same workload at every N); `value` of the '
+                             'N = 1 line is config 3, the largest configuration resident on one GPU')
+    return out
+
+
 def grid_setup(g, rank_seed):
     from image_stitcher_amd import placement, synth
     spec = synth.GridSpec(rows=g, cols=g, tile_h=TILE, tile_w=TILE, ov_y=OVERLAP, ov_x=OVERLAP,
@@ -300,8 +338,30 @@ def plane_digest(plane, rows_per_chunk=2048):
     return d
 
 
+ARENAS = []      # the DeviceArenas of this process's canvases (alloc_planes): their probe results go into the line
+
+
+def memory_info():
+    """What the line says about the memory under the canvas: the card's partition modes (sysfs) and the arena's classes."""
+    import glob
+    modes = {}
+    for key in ('current_memory_partition', 'current_compute_partition'):
+        vals = set()
+        for f in glob.glob(f'/sys/class/drm/card*/device/{key}'):
+            try:
+                with open(f) as fh:
+                    vals.add(fh.read().strip())
+            except OSError:
+                pass
+        modes[key.replace('current_', '')] = sorted(vals) or None
+    return dict(modes, canvas_arena=ARENAS[-1].info if ARENAS else None)
+
+
 def alloc_planes(n, g, hc, wc, dev, layout):
     """Tile stacks [n, g*g, TILE, TILE] and canvas slots [n, hc, wc] (uint16) for n planes.
+    'mixed': the canvas in a native.DeviceArena (every stretch of it lies over all three memory classes of the card, so the
+    fusion kernel's row-segment writes run at the spread-out rate wherever a plane starts; csrc/arena.hip, DESIGN.md 5.1
+    point 10), the tiles in a plain allocation.
     'arena': ONE allocation [canvas slot 0 | tile stack 0 | canvas slot 1 | tile stack 1 | ...]: the canvas slots then lie
     (canvas plane + tile stack) bytes apart, spread over all the memory the job holds, instead of side by side in an
     allocation of their own -- the planes of a group write fastest when they lie in different stretches of device memory
@@ -310,6 +370,14 @@ def alloc_planes(n, g, hc, wc, dev, layout):
     'separate': round 2's two allocations."""
     import torch
     from image_stitcher_amd import native
+    if layout == 'mixed':
+        # the canvas FIRST, while the card is empty: the arena takes up to three times its size, classifies it, keeps a third
+        # per memory class and gives the rest back (native.DeviceArena); the tiles then come from a plain allocation -- reads
+        # do not depend on the class
+        arena = native.DeviceArena(native.canvas_bytes(n, hc, wc, torch.uint16), dev)
+        canvas = native.empty_canvas(n, hc, wc, torch.uint16, dev, arena=arena)
+        ARENAS.append(arena)
+        return torch.empty((n, g * g, TILE, TILE), dtype=torch.uint16, device=dev), canvas
     if layout != 'arena':
         return torch.empty((n, g * g, TILE, TILE), dtype=torch.uint16, device=dev), native.empty_canvas(n, hc, wc, torch.uint16, dev)
     cplane = -(-(hc * wc * 2) // 4096) * 4096
@@ -528,6 +596,7 @@ def run_region(ctx):
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
         'config': {'workload': wl['desc'], 'planes_resident_per_gpu': n_planes,
                    'canvas': [hc, wc], 'tiles_per_plane': g * g, 'canvas_order': args.canvas_order, 'layout': args.layout,
+                   'memory': memory_info(),
                    'parallelism': f'one region per GPU x{world}, shift-table all-gather' if world > 1 else 'single GPU',
                    'shifts': {'h': list(state['shifts'].h_shift), 'v': list(state['shifts'].v_shift)},
                    'step': 'minmax + centre-pair PCC + span plan + one fusion launch over all planes; the next '
@@ -555,16 +624,21 @@ def run_region(ctx):
         del tiles, canvas, canvas_of_plane, ptrs, flat_list, slot_flats, flat_ptrs, reg_plane
         state.clear()
         fuse_events.clear()
+        import gc
+        gc.collect()
+        while ARENAS:      # the region's canvas arena goes back to the driver before the job builds its own
+            ARENAS.pop().close()
         torch.cuda.empty_cache()
         ref_args = argparse.Namespace(**dict(vars(args), steps=1, warmup=1, no_cpu_baseline=True, planes=0, batch=0, sha_out=None))
         job = run_job(dict(ctx, args=ref_args, wl=dict(WORKLOADS['cfg4'], name='cfg4')))
         out['headline_job_on_this_gpu'] = {
             'workload': job['config']['workload'], 'value': job['value'], 'unit': job['unit'], 'ms_per_step': job['ms_per_step'],
+            'wall_ms_per_job': job['wall_ms_per_job'],
             'steps': 1, 'warmup': 1, 'scaling_note': 'the N = 1 point of the strong-scaling curve that bench.py --gpus N measures',
             'resident_batches': job['config']['resident_batches_per_gpu'], 'roofline_frac': job['roofline']['frac'],
             'launch_ms': job['roofline']['launch_ms'], 'host_ms_per_job': job['host_ms_per_job_rank0'],
             'registration': job['config']['registration']}
-    return out
+    return with_scale_keys(out, out.get('headline_job_on_this_gpu'))
 
 
 def shift_parity(sh, truth):
@@ -775,9 +849,15 @@ def run_job(ctx):
     for _ in range(args.warmup):
         job(False)
     plans.clear()          # the first timed job plans and uploads like the first job of a real run
+    sync_all()
+    w0 = time.perf_counter()
     per_job = [job('last' if k + 1 == args.steps else True) for k in range(args.steps)]
     seconds = float(sum(per_job))
     sync_all()
+    # what a wall clock sees of the same K jobs: the timed pieces PLUS the device synthesis of every batch's tiles (the
+    # stand-in for reading them; 1.6 TiB cannot be resident) and the gaps between launches -- reported beside ms_per_step,
+    # never as `value` (--sha-out's digests would sit in it too: that option is for the N-rank == 1-rank check)
+    wall = time.perf_counter() - w0
     if args.sha_out:
         with open(f'{args.sha_out}.rank{rank}', 'w') as fh:
             json.dump(state.get('sha', {}), fh)
@@ -785,9 +865,9 @@ def run_job(ctx):
     first_job = per_job[0]
     steady = float(np.mean(per_job[1:])) if len(per_job) > 1 else None
     if multi:      # the job's time is the slowest rank's: MAX over ranks of the sum and of the first job
-        t = torch.tensor([seconds, first_job, steady if steady is not None else 0.0], dtype=torch.float64, device=coll_dev or 'cpu')
+        t = torch.tensor([seconds, first_job, steady if steady is not None else 0.0, wall], dtype=torch.float64, device=coll_dev or 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seconds, first_job = float(t[0].item()), float(t[1].item())
+        seconds, first_job, wall = float(t[0].item()), float(t[1].item()), float(t[3].item())
         steady = float(t[2].item()) if steady is not None else None
 
     plan, shifts = state['plan'], state['shifts']
@@ -809,6 +889,9 @@ def run_job(ctx):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(seconds / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'u16', 'data': 'synthetic',
+        'wall_ms_per_job': round(wall / args.steps * 1e3, 3),
+        'wall_note': 'perf_counter around the K timed jobs, MAX over ranks: ms_per_step plus the device synthesis of every batch\'s tiles '
+                     '(stand-in for reading them: 1.6 TiB cannot be resident) and the gaps between launches',
         'first_job_ms': round(first_job * 1e3, 3), 'steady_job_ms': None if steady is None else round(steady * 1e3, 3),
         'first_job_note': 'the first timed job builds the fusion plan (cache emptied after the warm-up: host sweep into spans + work list '
                           'expanded on the device, or --host-plan: host planner + upload); the later ones re-use it while the shifts '
@@ -820,8 +903,8 @@ def run_job(ctx):
                                     'all-gathered, per-axis median') if all_pairs else
                                    "the reference's centre pairs on rank 0 (stitcher.py:455-485), 8-int32 row all-gathered",
                    'resident_batches_per_gpu': [len(b) for b in batches], 'canvas': [hc, wc], 'tiles_per_plane': g * g, 'layout': args.layout,
-                   'parallelism': f'planes dealt over {world} GPUs in contiguous runs (a channel\'s z planes stay together), rank 0 registers, '
-                                  f'shift row all-gathered over {"RCCL" if ctx["backend"] == "nccl" else ctx["backend"]}, no image data exchanged',
+                   'memory': memory_info(),
+                   'parallelism': parallelism_text(world, ctx['backend'], all_pairs),
                    'shifts': {'h': list(shifts.h_shift), 'v': list(shifts.v_shift)},
                    'step': 'the whole job: registration + all-gather + span plan (kept while the shifts stay), then per '
                            'resident batch one fusion launch; a batch\'s tiles are synthesised on the device before its launch, '
@@ -845,7 +928,8 @@ def run_job(ctx):
         base, check = cpu_baseline_fusion_only(tiles[:len(b)], flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas[:len(b)])
         out['cpu_baseline'], out['cpu_baseline_reference'] = base, REFERENCE_TIMING
         out['parity'].update(check)
-    return out
+    return with_scale_keys(out, {'workload': wl['desc'] + ('' if total_planes == C * Z else f' [cut to {total_planes} of {C * Z} planes]'), 'value': out['value'], 'unit': out['unit'], 'ms_per_step': out['ms_per_step'],
+                                 'wall_ms_per_job': out['wall_ms_per_job']})
 
 
 def cpu_baseline_fusion_only(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas, max_planes=2):

@@ -21,7 +21,9 @@ SQ_U8, SQ_U16, SQ_F32, SQ_F64 = 1, 2, 4, 8
 SQ_FUSE_OVERWRITE, SQ_FUSE_FEATHER = 0, 1
 SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
 SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS, SQ_FUSE_CONSECUTIVE_GROUPS = 1, 2, 4, 8, 16
-SQ_VERSION = 106
+SQ_VERSION = 107
+SQ_ARENA_NATURAL_ORDER = 1
+SQ_ARENA_MAX_CLASSES = 8
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
                        ('dst_y', '<i4'), ('dst_x', '<i4')])
@@ -63,6 +65,13 @@ class _RegisterArgs(C.Structure):
     ]
 
 
+class _ArenaInfo(C.Structure):
+    _fields_ = [('base_dev', C.c_void_p), ('bytes', C.c_int64), ('slice_bytes', C.c_int64), ('n_slices', C.c_int32),
+                ('n_candidates', C.c_int32), ('n_classes', C.c_int32), ('class_slices', C.c_int32 * 8),
+                ('class_candidates', C.c_int32 * 8), ('interleaved', C.c_int32),
+                ('probe_ms', C.c_float), ('create_ms', C.c_float), ('min_pair_gbs', C.c_float), ('max_pair_gbs', C.c_float)]
+
+
 class _BasicInfo(C.Structure):
     _fields_ = [('reweight_iterations', C.c_int32), ('ladmap_iterations', C.c_int32), ('working_size', C.c_int32)]
 
@@ -95,6 +104,9 @@ EXPORTS = {
     'sq_selftest_normalise_divide': (C.c_int, [C.c_void_p, C.c_void_p]),
     'sq_selftest_blend_divide': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'sq_fuse_scratch_bytes': (C.c_int64, [C.c_int32]),
+    'sq_arena_create': (C.c_void_p, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(_ArenaInfo)]),
+    'sq_arena_info_get': (C.c_int, [C.c_void_p, C.POINTER(_ArenaInfo)]),
+    'sq_arena_destroy': (C.c_int, [C.c_void_p]),
     'sq_blosc_chunk_count': (C.c_int64, [C.c_int32] * 5),
     'sq_blosc_out_bound': (C.c_int64, [C.c_int32] * 6),
     'sq_blosc_scratch_bytes': (C.c_int64, [C.c_int32] * 6),
@@ -396,18 +408,121 @@ def fuse_planes(plan: FusePlan, tiles, canvas, flats=None, tile_ptrs=None, strea
 PLANE_ALIGN_BYTES = 128
 
 
-def empty_canvas(n_planes: int, hc: int, wc: int, dtype, device):
+class _RawDeviceMemory:
+    """A range of an arena as an object PyTorch can alias (``__cuda_array_interface__``, uint8); keeps the arena alive."""
+
+    def __init__(self, arena, ptr: int, nbytes: int):
+        self._arena = arena
+        self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(ptr), False), 'version': 2}
+
+
+class DeviceArena:
+    """Device memory whose every stretch lies over all memory classes of the card (sq_arena_create, csrc/arena.hip): the
+    home of fusion canvases.  An MI355X's memory falls into three classes of a third of the card each; the fusion kernel's
+    row-segment writes run at 0.55 of the HBM peak inside one class and at 0.73-0.76 spread over them, and a plain
+    allocation gets runs of tens of GiB of ONE class.  The arena takes physical slices, measures their classes and maps them
+    round-robin into one virtual range, so a canvas carved from it is fast wherever it starts.
+
+    ``take(nbytes)`` bump-allocates (512-byte aligned) and returns a uint8 tensor aliasing the range; ``reset()`` starts
+    over (the caller makes sure nothing uses the old tensors any more); ``close()`` unmaps and releases everything."""
+
+    def __init__(self, nbytes: int, device=None, slice_bytes: int = 0, unit_bytes: int = 0, natural_order: bool = False, stream=None,
+                 candidate_bytes: Optional[int] = None):
+        import torch
+        L = lib()
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        info = _ArenaInfo()
+        with torch.cuda.device(self.device):
+            if candidate_bytes is None:
+                # memory comes in runs of tens of GiB of one class: take up to three times what is needed -- or what is free
+                # but for a reserve -- classify it, keep a third per class and give the rest back (create the arena FIRST,
+                # while the card is empty)
+                free = torch.cuda.mem_get_info(self.device)[0]
+                candidate_bytes = max(int(nbytes), min(3 * int(nbytes), free - (6 << 30)))
+            self._h = L.sq_arena_create(int(nbytes), int(candidate_bytes), int(slice_bytes), int(unit_bytes),
+                                        SQ_ARENA_NATURAL_ORDER if natural_order else 0, _stream_ptr(stream), C.byref(info))
+        if not self._h:
+            raise NativeError(f"sq_arena_create({nbytes} bytes) failed: {L.sq_last_error().decode()}")
+        self.base, self.nbytes = int(info.base_dev), int(info.bytes)
+        self.info = {'bytes': self.nbytes, 'slice_bytes': int(info.slice_bytes), 'n_slices': int(info.n_slices),
+                     'n_candidates': int(info.n_candidates), 'n_classes': int(info.n_classes),
+                     'class_slices': [int(v) for v in info.class_slices[:max(1, info.n_classes)]],
+                     'class_candidates': [int(v) for v in info.class_candidates[:max(1, info.n_classes)]],
+                     'interleaved': bool(info.interleaved), 'probe_ms': round(float(info.probe_ms), 2),
+                     'create_ms': round(float(info.create_ms), 1), 'min_pair_gbs': round(float(info.min_pair_gbs), 1),
+                     'max_pair_gbs': round(float(info.max_pair_gbs), 1)}
+        self._used = 0
+        self._holders = []
+
+    def take(self, nbytes: int, align: int = 512):
+        """uint8 device tensor of ``nbytes`` bytes at the next ``align``-byte boundary of the arena."""
+        import torch
+        if not self._h:
+            raise NativeError("DeviceArena is closed")
+        start = -(-self._used // align) * align
+        if start + nbytes > self.nbytes:
+            raise NativeError(f"DeviceArena: {nbytes} bytes asked, {self.nbytes - start} of {self.nbytes} left")
+        self._used = start + int(nbytes)
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        # PyTorch keeps the holder alive for as long as the tensor's STORAGE lives (views included) and nobody else holds it:
+        # a weak reference to it says whether the range is still in use
+        import weakref
+        holder = _RawDeviceMemory(self, self.base + start, nbytes)
+        self._holders.append(weakref.ref(holder))
+        return torch.as_tensor(holder, device=self.device)
+
+    def in_use(self) -> bool:
+        """True while any tensor taken since the last ``reset()`` (or a view of one) is alive."""
+        self._holders = [h for h in self._holders if h() is not None]
+        return bool(self._holders)
+
+    @property
+    def free_bytes(self) -> int:
+        return self.nbytes - self._used
+
+    def reset(self) -> None:
+        self._used = 0
+        self._holders = []
+
+    def close(self) -> None:
+        if getattr(self, '_h', None):
+            lib().sq_arena_destroy(self._h)      # waits for the device: nothing may be writing into memory that goes away
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def empty_canvas(n_planes: int, hc: int, wc: int, dtype, device, arena: Optional['DeviceArena'] = None):
     """Uninitialised device canvas [n_planes, hc, wc] with dense rows (pitch = wc, like the reference's array)
     whose PLANE stride is rounded up to a multiple of 128 bytes: every plane then starts on a cache-line
     boundary, so the rows of all planes sit at the same phase inside a line and the fusion kernel can carry the
     planes that share a gain image through an item together (fuse.hip, plane groups).  Each plane ``canvas[p]`` is
-    contiguous; the tensor as a whole is not."""
+    contiguous; the tensor as a whole is not.  ``arena``: carve it from this DeviceArena (memory mapped over all
+    memory classes of the card: where the fusion kernel writes fastest) instead of a plain allocation."""
     import torch
     esz = torch.empty((), dtype=dtype).element_size()
     unit = PLANE_ALIGN_BYTES // esz
     stride = -(-(hc * wc) // unit) * unit
-    flat = torch.empty(max(1, n_planes * stride), dtype=dtype, device=device)
+    if arena is not None:
+        flat = arena.take(max(1, n_planes * stride) * esz).view(dtype)
+    else:
+        flat = torch.empty(max(1, n_planes * stride), dtype=dtype, device=device)
     return flat.as_strided((n_planes, hc, wc), (stride, wc, 1))
+
+
+def canvas_bytes(n_planes: int, hc: int, wc: int, dtype) -> int:
+    """Bytes ``empty_canvas`` takes for this shape (plane stride padded to 128 bytes, start aligned to 512)."""
+    import torch
+    esz = torch.empty((), dtype=dtype).element_size()
+    unit = PLANE_ALIGN_BYTES // esz
+    return max(1, n_planes * (-(-(hc * wc) // unit) * unit)) * esz + 512
 
 
 def planes_to_host(canvas):

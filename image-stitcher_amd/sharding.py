@@ -160,7 +160,8 @@ def all_gather_pair_table(local_rows: np.ndarray, n_pairs: int, rank: int, world
     the pair list and contributes its [k_r, 3] float64 rows {dy, dx, err}; every rank gets the whole [n_pairs, 3] table
     back in pair order.  Runs differ in length by at most one, so the rows travel in equal slots of ceil(n_pairs /
     world) rows (the spare one NaN) through ONE all_gather_into_tensor -- 32x32 grid: 1984 pairs x 24 B = 47 KB,
-    latency-bound over xGMI.  Single process: the input."""
+    latency-bound over xGMI.  ``world == 1`` (a single process, or one rank of a
+    larger run registering a region on its own): the input, no collective."""
     import torch
     import torch.distributed as dist
     import os
@@ -168,8 +169,12 @@ def all_gather_pair_table(local_rows: np.ndarray, n_pairs: int, rank: int, world
     mine = contiguous_blocks(n_pairs, rank, world)
     if len(local_rows) != len(mine):
         raise ValueError(f"rank {rank} owns {len(mine)} of {n_pairs} pairs but brought {len(local_rows)} rows")
-    if not (dist.is_available() and dist.is_initialized()) or \
-            (dist.get_world_size(group) == 1 and not os.environ.get('SQ_DIST_FORCE_COLLECTIVE')):
+    # world == 1 means "this caller registered every pair itself": no collective, whatever process group exists around it
+    # (a rank of an N-rank run that registers one of ITS OWN regions -- per-region registration with the regions dealt to
+    # the ranks -- is such a caller; comparing its world of 1 with the group's N used to raise on every rank)
+    if world == 1 and not os.environ.get('SQ_DIST_FORCE_COLLECTIVE'):
+        return local_rows.copy()
+    if not (dist.is_available() and dist.is_initialized()):
         if world != 1:
             raise RuntimeError(f"world of {world} ranks but no process group: nothing to gather the pair table over")
         return local_rows.copy()

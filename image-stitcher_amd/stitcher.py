@@ -55,7 +55,8 @@ class Signal:
 class Stitcher:
     def __init__(self, params: StitchingParameters, device=None, fusion_mode: str = 'overwrite',
                  normalization: Optional[str] = 'phase', zarr_compression: str = 'blosc',
-                 per_region_registration: bool = False, flatfield_estimator: str = 'auto'):
+                 per_region_registration: bool = False, flatfield_estimator: str = 'auto',
+                 all_pairs_registration: bool = False):
         self.update_progress = Signal(int, int)
         self.getting_flatfields = Signal()
         self.starting_stitching = Signal()
@@ -76,7 +77,7 @@ class Stitcher:
         if self.use_registration:
             self.registration_channel = params.registration_channel
             self.registration_z_level = params.registration_z_level
-            self.dynamic_registration = params.dynamic_registration
+            self.dynamic_registration = params.dynamic_registration   # stored and never read, like the reference (stitcher.py:92)
         self.scan_pattern = params.scan_pattern
         if fusion_mode not in ('overwrite', 'feather'):
             raise ValueError("fusion_mode must be 'overwrite' or 'feather'")
@@ -94,10 +95,21 @@ class Stitcher:
         # reference, stitcher.py:1244-1246).  True: every (timepoint, region) is registered on its own
         # tiles before it is fused (BASELINE config 5: per-well registration).
         self.per_region_registration = bool(per_region_registration) and self.use_registration
+        # Extension of this build (the north star's batched registration), behind a flag of its own: every adjacent pair of
+        # the registration plane, per-axis median.  The reference's --dynamic-registration is parsed, stored and ignored
+        # (stitcher.py:92, stitcher_parameters.py:24), so that flag keeps the centre-pair result here too.
+        self.all_pairs_registration = bool(all_pairs_registration) and self.use_registration
         self.batch_bytes_limit = 4 << 30          # tile bytes staged (pinned + device) per ingest batch
         self._device = device
         self._plan_cache: Dict[tuple, native.FusePlan] = {}
         self._buffer_cache: Dict[tuple, object] = {}
+        # the canvas' home: device memory mapped over all memory classes of the card (native.DeviceArena), kept for the next
+        # region; canvases below canvas_arena_min_bytes (and every canvas when the platform lacks virtual memory
+        # management) come from a plain allocation
+        self.canvas_arena_min_bytes = int(os.environ.get('SQ_CANVAS_ARENA_MIN_BYTES', 2 << 30))
+        self._arena = None
+        self._arena_unsupported = False
+        self.canvas_arena_info = None
         self.init_stitching_parameters()
 
     # ------------------------------------------------------------------ state
@@ -354,9 +366,10 @@ class Stitcher:
             self.pixel_size_um, self.pixel_binning)
         print(f"[registration] crop widths from the stage pitch: {max_x_overlap} px horizontal, {max_y_overlap} px vertical")
         registration.check_crop_lengths(self.input_height, self.input_width, max_x_overlap, max_y_overlap)
-        if getattr(self, 'dynamic_registration', False):
-            # --dynamic-registration (parsed but never read by the reference): every adjacent pair of
-            # the registration plane, one batch per direction, per-axis median of the integer shifts
+        if self.all_pairs_registration:
+            # --all-pairs-registration (an addition of this build; NOT the reference's --dynamic-registration, which it
+            # parses and never reads): every adjacent pair of the registration plane, one batch per direction, per-axis
+            # median of the integer shifts
             self._calculate_shifts_all_pairs(t, region, x_positions, y_positions, max_x_overlap, max_y_overlap)
             print(f"[registration] all pairs: h_shift = {self.h_shift}, v_shift = {self.v_shift}")
             return
@@ -548,6 +561,36 @@ class Stitcher:
                                                            expand_on_device=len(rects) >= 64)
         return plan
 
+    def _empty_canvas(self, n_planes, hc, wc, tdtype):
+        """The canvas of ``stitch_planes`` ([n_planes, hc, wc], planes on 128-byte lines, never zero-filled: stitcher.py:356-362's
+        da.zeros is written by the fusion kernel).  From ``canvas_arena_min_bytes`` up it is carved from a DeviceArena --
+        physical slices classified by a probe and mapped round-robin over the card's memory classes, so the kernel's
+        row-segment writes run at the spread-out rate (0.71 instead of 0.61-0.69 of the HBM peak on config 3, and the same
+        on every box; csrc/arena.hip) -- created before the ingest buffers, while the card has memory to choose from, and
+        reused for the next region once this region's canvas has been dropped."""
+        need = native.canvas_bytes(n_planes, hc, wc, tdtype)
+        if need < self.canvas_arena_min_bytes or self._arena_unsupported:
+            return native.empty_canvas(n_planes, hc, wc, tdtype, self.device)
+        busy = self._arena is not None and self._arena.in_use()      # a caller still holds the last canvas: leave it alone
+        if self._arena is None or busy or self._arena.nbytes < need:
+            if self._arena is not None and not busy:
+                self._arena.close()
+            self._arena = None
+            try:
+                self._arena = native.DeviceArena(need, self.device)
+            except native.NativeError as exc:
+                if 'virtual memory management unsupported' not in str(exc):
+                    raise
+                print(f"[canvas] no virtual memory management on this platform ({exc}); the canvas comes from a plain allocation")
+                self._arena_unsupported = True
+                return native.empty_canvas(n_planes, hc, wc, tdtype, self.device)
+            self.canvas_arena_info = self._arena.info
+            print(f"[canvas] arena of {self._arena.nbytes / 2**30:.1f} GiB over {self._arena.info['n_classes']} memory classes "
+                  f"{self._arena.info['class_slices']} (slices of {self._arena.info['slice_bytes'] >> 20} MiB), "
+                  f"{self._arena.info['create_ms']:.0f} ms")
+        self._arena.reset()
+        return native.empty_canvas(n_planes, hc, wc, tdtype, self.device, arena=self._arena)
+
     def _tile_rect(self, tile_info):
         """sq_rect of one file: placement (stitcher.py:656-679) + crop (:570-587)."""
         if self.use_registration:
@@ -620,14 +663,12 @@ class Stitcher:
         print(f"region {region} timepoint {timepoint} output array dimensions: "
               f"{(1, self.num_c, self.num_z, height, width)}" + ("" if only_planes is None else f", planes {plane_ids}"))
         # dense rows like the reference's array, every plane on a 128-byte line (native.empty_canvas)
-        flat_canvas = None if stream_to is not None else \
-            native.empty_canvas(len(plane_ids), height, width, native.torch_dtype_of(self.dtype), self.device)
         y0, y1 = (0, height) if row_band is None else (int(row_band[0]), int(row_band[1]))
         if not (0 <= y0 < y1 <= height):
             raise ValueError(f"row band {row_band} outside the {height}-row canvas")
         hc, wc = y1 - y0, width
-        if flat_canvas is not None and row_band is not None:
-            flat_canvas = native.empty_canvas(len(plane_ids), hc, wc, native.torch_dtype_of(self.dtype), self.device)
+        flat_canvas = None if stream_to is not None else \
+            self._empty_canvas(len(plane_ids), hc, wc, native.torch_dtype_of(self.dtype))
         th, tw = self.input_height, self.input_width
         total_tiles = len(region_data)
         print(f"Beginning stitching of {total_tiles} tiles for region {region} timepoint {timepoint}")
@@ -942,10 +983,10 @@ class Stitcher:
                 with open(os.path.join(self.output_folder, 'flatfield_info.json'), 'w') as fh:
                     json.dump(self.flatfield_info, fh, indent=1)
         coll = sharding.collective_device(self)
-        # all-pairs registration (--dynamic-registration) is sharded by PAIR: every rank registers its run of the pair
+        # all-pairs registration (--all-pairs-registration) is sharded by PAIR: every rank registers its run of the pair
         # list and the float64 pair table is all-gathered (registration.register_all_pairs_sharded); the reference's
         # centre-pair scheme is three tiles' worth of work and stays on rank 0, its 8-int32 row all-gathered
-        pair_sharded = world > 1 and bool(getattr(self, 'dynamic_registration', False))
+        pair_sharded = world > 1 and self.all_pairs_registration
         if self.use_registration and not self.per_region_registration:
             if rank == 0 or pair_sharded:
                 print(f"\nCalculating shifts on region {self.regions[0]}...")

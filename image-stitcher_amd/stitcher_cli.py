@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Command line of the stitcher: the reference's flags (stitcher_cli.py:14-62) unchanged,
-plus five switches for what this build adds (``--fusion-mode``, ``--normalization``,
-``--zarr-compression``, ``--per-region-registration``, ``--flatfield-estimator``).
+plus six switches for what this build adds (``--fusion-mode``, ``--normalization``,
+``--zarr-compression``, ``--per-region-registration``, ``--flatfield-estimator``, ``--all-pairs-registration``).
 
     python -m image_stitcher_amd.stitcher_cli -i /path/to/acquisition -r -ff --registration-channel "488"
 """
@@ -20,7 +20,7 @@ FLAGS = (
     (('--use-registration', '-r'), dict(action='store_true', help="register the centre tile pairs and place tiles by the measured shifts")),
     (('--registration-channel',), dict(help="channel the shifts are measured on (first channel when omitted)")),
     (('--registration-z-level',), dict(type=int, default=0, help="z plane the shifts are measured on")),
-    (('--dynamic-registration',), dict(action='store_true', help="register every adjacent tile pair and use the median shift (the reference accepts and ignores this flag)")),
+    (('--dynamic-registration',), dict(action='store_true', help="accepted, stored and ignored, exactly like the reference (stitcher.py:92); see --all-pairs-registration")),
     (('--scan-pattern', '-s'), dict(choices=['Unidirectional', 'S-Pattern'], default='Unidirectional', help="stage scan order")),
     (('--merge-timepoints', '-mt'), dict(action='store_true', help="request one dataset over all timepoints")),
     (('--merge-hcs-regions', '-mw'), dict(action='store_true', help="request one plate dataset over all wells")),
@@ -35,6 +35,10 @@ FLAGS = (
                                         "on the device; zlib = host threads; none = raw chunks")),
     (('--per-region-registration',), dict(action='store_true',
                                           help="with -r: register every (timepoint, region) on its own tiles instead of once")),
+    (('--all-pairs-registration',), dict(action='store_true',
+                                         help="with -r: register EVERY adjacent tile pair of the registration plane (batched on the device, "
+                                              "sharded by pair over the ranks) and place tiles by the per-axis median shift, instead of the "
+                                              "reference's centre-tile pairs")),
     (('--flatfield-estimator',), dict(choices=['auto', 'basic', 'basicpy', 'mean'], default='auto',
                                       help="with -ff: basicpy's BaSiC fit when that package is installed (auto / basicpy), this "
                                            "build's device restatement of the published BaSiC fit (basic; what auto falls back "
@@ -90,7 +94,8 @@ def main(argv=None):
                             normalization=None if args.normalization == 'none' else 'phase',
                             zarr_compression=args.zarr_compression,
                             per_region_registration=args.per_region_registration,
-                            flatfield_estimator=args.flatfield_estimator)
+                            flatfield_estimator=args.flatfield_estimator,
+                            all_pairs_registration=args.all_pairs_registration)
         print("Starting stitching with parameters:")
         for k, v in params.to_dict().items():
             print(f"{k}: {v}")

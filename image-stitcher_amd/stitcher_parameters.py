@@ -31,8 +31,8 @@ class StitchingParameters:
                                 placed by their stage coordinates
     ``registration_channel``    channel the shifts are measured on
     ``registration_z_level``    z plane the shifts are measured on
-    ``dynamic_registration``    (the reference parses and ignores it) register ALL adjacent pairs of the
-                                registration plane on the device and use the per-axis median of the shifts
+    ``dynamic_registration``    parsed, stored and ignored -- exactly what the reference does with it
+                                (stitcher.py:92); all-pairs registration is ``Stitcher(all_pairs_registration=True)``
     ``scan_pattern``            ``S-Pattern`` adds a third pair so that reversed stage rows get their own shift
     ``merge_timepoints`` /      output re-packaging requests; the per-(timepoint, region) stores are always
     ``merge_hcs_regions``       written
@@ -44,7 +44,7 @@ class StitchingParameters:
     use_registration: bool = False
     registration_channel: str = ''      # '' = first channel in sorted order
     registration_z_level: int = 0
-    dynamic_registration: bool = False  # all-pairs median registration (the reference stores and ignores it)
+    dynamic_registration: bool = False  # stored and ignored, like the reference (stitcher.py:92)
     scan_pattern: str = SCAN_PATTERNS[0]
     merge_timepoints: bool = False
     merge_hcs_regions: bool = False

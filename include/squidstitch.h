@@ -9,7 +9,9 @@
  * Conventions
  *  - `extern "C"`, plain C types.  No torch types, no C++ types.
  *  - Every `*_dev` pointer is a DEVICE pointer owned by the caller (e.g. a PyTorch-ROCm
- *    tensor's data_ptr()).  The library never allocates, frees or keeps caller memory.
+ *    tensor's data_ptr()).  The library never allocates, frees or keeps caller memory
+ *    (the one exception is explicit: sq_arena_create hands out device memory the caller asked
+ *    for and gives back with sq_arena_destroy).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All device work
  *    is enqueued on it and is asynchronous; no entry point synchronises.
  *  - Return value: 0 = OK, negative = sq_status.  sq_last_error() gives the thread-local
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 106 /* 0.1.5: sq_selftest_normalise_divide; 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
+#define SQ_VERSION 107 /* 0.1.6: sq_arena_* (canvas memory mapped over all memory classes of the card); 0.1.5: sq_selftest_normalise_divide; 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -151,6 +153,48 @@ int64_t sq_fuse_scratch_bytes(int32_t n_planes);
 /* Fuse n_planes planes.  Every canvas voxel is written exactly once (uncovered voxels = 0,
  * the reference starts from da.zeros, stitcher.py:362); no atomics; deterministic. */
 int sq_fuse_planes(const sq_fuse_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Canvas memory.  Replaces the allocation behind Stitcher.init_output (stitcher.py:356-362: the reference's canvas is a
+ * lazy dask array; here it is device memory the fusion kernel writes once).  WHERE that memory lies decides how fast the
+ * kernel can write it: MI355X device memory falls into three classes of a third of the card each, a row-segment write
+ * stream confined to one class runs at 0.55 of the HBM peak and at 0.73-0.76 when spread over the classes, and hipMalloc
+ * hands out runs of tens of GiB of one class (csrc/arena.hip).  sq_arena_create takes `bytes` of device
+ * memory in physical slices (hipMemCreate), measures which class every 512 MiB unit of them lies in (a pair-fill probe,
+ * ~0.3 s for 100 GiB, on `stream`), and maps the slices into ONE contiguous virtual range round-robin over the classes:
+ * any canvas laid out in [base_dev, base_dev + bytes) then has all classes under every ~200 MB of it, whatever its plane
+ * stride and however the planes are grouped.  The caller sub-allocates (the arena is a flat range; canvases want their
+ * planes on 128-byte lines, see sq_fuse_args) and destroys it when no kernel uses it any more.  Synchronises `stream`.
+ * Tiles, gains and plans may live anywhere: reads do not depend on the class.
+ *   candidate_bytes: memory taken and classified before `bytes` of it are chosen, a third per class, and the rest given
+ *       back (0 = bytes: whatever comes).  Memory comes in runs of tens of GiB of one class, so an arena is only balanced
+ *       when it can choose: 3 x bytes -- or what is free -- while the card is still empty, i.e. create the arena FIRST.
+ *   slice_bytes: 0 = 64 MiB (a multiple of 2 MiB);  unit_bytes: 0 = 512 MiB (a multiple of the slice, >= 16 MiB)
+ *   flags: SQ_ARENA_NATURAL_ORDER = skip the probe and keep the slices in creation order (the control of A/B runs)
+ * Returns NULL on failure (sq_last_error; SQ_ERR_UNSUPPORTED in the message when the platform lacks virtual memory
+ * management: allocate the canvas any other way then -- every entry point takes plain device pointers).
+ * ---------------------------------------------------------------------------------------- */
+#define SQ_ARENA_MAX_CLASSES 8
+typedef enum sq_arena_flags { SQ_ARENA_NATURAL_ORDER = 1 } sq_arena_flags;
+typedef struct sq_arena sq_arena;
+typedef struct sq_arena_info {
+    void *base_dev;       /* first byte of the arena (2 MiB aligned at least)                     */
+    int64_t bytes;        /* size, rounded up to whole slices                                     */
+    int64_t slice_bytes;
+    int32_t n_slices;
+    int32_t n_candidates; /* slices taken and classified (>= n_slices); the ones not chosen were given back */
+    int32_t n_classes;    /* populations the probe told apart (3 on an MI355X when the arena spans them; 1 = nothing to interleave) */
+    int32_t class_slices[SQ_ARENA_MAX_CLASSES];     /* slices of the arena per class     */
+    int32_t class_candidates[SQ_ARENA_MAX_CLASSES]; /* slices taken per class            */
+    int32_t interleaved;  /* 1: slices mapped round-robin over the classes; 0: creation order */
+    float probe_ms;       /* device time of the classification                                   */
+    float create_ms;      /* host time of the whole call                                         */
+    float min_pair_gbs, max_pair_gbs; /* slowest / fastest pair fill seen by the probe, GB/s written */
+} sq_arena_info;
+sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int64_t slice_bytes, int64_t unit_bytes, int32_t flags,
+                          void *stream, sq_arena_info *info);
+int sq_arena_info_get(const sq_arena *arena, sq_arena_info *info);
+int sq_arena_destroy(sq_arena *arena);
 
 /* ------------------------------------------------------------------------------------------
  * Pyramid: one level of the OME-Zarr multiscale image from the level before.  Replaces

@@ -1,0 +1,157 @@
+"""The canvas arena (sq_arena_create, csrc/arena.hip): device memory taken in physical slices, classified by a pair-fill probe and
+mapped round-robin over the card's memory classes.  Whatever the mapping, it is plain device memory to every kernel: fusion into a
+canvas carved from it gives the reference's voxels (golden canvases, oracle), tensors alias it, and it goes away cleanly."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_case, spec_of
+from image_stitcher_amd import native, placement, synth
+from oracle import stitch_oracle as O
+
+pytestmark = pytest.mark.gpu
+MiB = 1 << 20
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+def test_arena_is_classified_balanced_and_aliases_like_plain_memory():
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    # 256 MiB chosen from 768 MiB of candidates: 8 MiB slices, 32 MiB probe units (the production sizes are 64 / 512 MiB)
+    arena = native.DeviceArena(256 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=768 * MiB)
+    info = arena.info
+    assert info['bytes'] == 256 * MiB == arena.nbytes and info['n_slices'] == 32 and info['n_candidates'] == 96
+    assert 1 <= info['n_classes'] <= native.SQ_ARENA_MAX_CLASSES
+    assert sum(info['class_slices']) == 32 and sum(info['class_candidates']) == 96
+    assert info['interleaved'] == (info['n_classes'] > 1) and info['probe_ms'] > 0 and info['max_pair_gbs'] >= info['min_pair_gbs'] > 0
+    if info['n_classes'] > 1:      # round-robin: no class gives more than its share + 1 while another still has candidates
+        fair = -(-32 // info['n_classes'])
+        for have, took in zip(info['class_candidates'], info['class_slices']):
+            assert took <= max(fair, 32 - sum(min(c, fair) for c in info['class_candidates']) + fair)
+            assert took <= have
+    assert arena.base % (2 * MiB) == 0
+    # every byte of the range is writable and readable, across slice boundaries, and distinct (no slice mapped twice)
+    whole = arena.take(arena.nbytes).view(torch.int64)
+    assert whole.data_ptr() == arena.base and arena.free_bytes == 0
+    whole.copy_(torch.arange(whole.numel(), dtype=torch.int64, device=dev))
+    torch.cuda.synchronize()
+    assert bool((whole[1:] - whole[:-1] == 1).all()) and int(whole[-1].item()) == whole.numel() - 1
+    probe = whole[(8 * MiB // 8) - 2:(8 * MiB // 8) + 2].cpu().numpy()      # straddles the first slice boundary
+    np.testing.assert_array_equal(probe, np.arange(8 * MiB // 8 - 2, 8 * MiB // 8 + 2))
+    with pytest.raises(native.NativeError, match='left'):
+        arena.take(1)
+    assert arena.in_use()
+    del whole
+    assert not arena.in_use()
+    arena.reset()
+    # bump allocation: aligned, disjoint, views keep the range "in use"
+    a = arena.take(1000)
+    b = arena.take(24, align=4096)
+    assert a.data_ptr() == arena.base and b.data_ptr() == arena.base + 4096 and a.dtype == torch.uint8
+    v = b.view(torch.uint16)[3:7]
+    del a, b
+    assert arena.in_use()
+    del v
+    assert not arena.in_use()
+    arena.close()
+    arena.close()      # idempotent
+    with pytest.raises(native.NativeError, match='closed'):
+        arena.take(1)
+    # the control: slices in creation order, no probe
+    nat = native.DeviceArena(64 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, natural_order=True)
+    assert nat.info['n_classes'] == 1 and not nat.info['interleaved'] and nat.info['n_candidates'] == 8 and nat.info['probe_ms'] == 0
+    nat.close()
+    with pytest.raises(native.NativeError, match='multiple of 2 MiB'):
+        native.DeviceArena(64 * MiB, dev, slice_bytes=3 * MiB)
+    with pytest.raises(native.NativeError, match='positive'):
+        native.DeviceArena(0, dev)
+
+
+def test_stitcher_uses_the_arena_and_reuses_it(tmp_path, monkeypatch):
+    """Stitcher.stitch_region with the arena forced on for a small golden acquisition: the reference's canvas, the arena kept for
+    the next region, left alone while a caller still holds the last device canvas, and a plain allocation below the threshold."""
+    torch = _torch()
+    from image_stitcher_amd.stitcher import Stitcher
+    from image_stitcher_amd.stitcher_parameters import StitchingParameters
+    info, arrays = load_case('reg_multi')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    monkeypatch.setenv('SQ_CANVAS_ARENA_MIN_BYTES', '1')
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    assert st.canvas_arena_min_bytes == 1
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    st.calculate_shifts(st.timepoints[0], st.regions[0])
+    keys = list(info['canvases'])
+    first = None
+    for key in keys:
+        t, region = key[1:].split('_', 1)
+        got = st.stitch_region(int(t), region)
+        np.testing.assert_array_equal(got, arrays[f'{key}_canvas'])
+        assert st._arena is not None and not st._arena.in_use()      # the host copy left: the arena is free for the next region
+        first = first or st._arena
+        assert st._arena is first                                     # ... and it IS reused
+    assert st.canvas_arena_info['n_slices'] >= 1
+    # a caller that keeps the device canvas: the next region must not overwrite it
+    t, region = keys[0][1:].split('_', 1)
+    held = st.stitch_region(int(t), region, device_output=True)
+    assert st._arena.in_use()
+    t2, region2 = keys[1][1:].split('_', 1)
+    other = st.stitch_region(int(t2), region2)
+    assert st._arena is not first
+    np.testing.assert_array_equal(other, arrays[f'{keys[1]}_canvas'])
+    np.testing.assert_array_equal(held.cpu().numpy(), arrays[f'{keys[0]}_canvas'])
+    del held
+    # below the threshold: a plain allocation, no arena
+    plain = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    plain.canvas_arena_min_bytes = 1 << 40
+    plain.get_timepoints(); plain.extract_acquisition_parameters(); plain.get_pixel_size(); plain.parse_acquisition_metadata()
+    plain.calculate_shifts(plain.timepoints[0], plain.regions[0])
+    np.testing.assert_array_equal(plain.stitch_region(int(t), region), arrays[f'{keys[0]}_canvas'])
+    assert plain._arena is None
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_plane_groups_into_an_arena_canvas_equal_the_oracle(seed):
+    """Random geometry, several planes that share gains (plane groups + seam owners + device queues), canvas carved from an
+    arena at an odd offset: every voxel the oracle's, the padding between the planes untouched."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(100 + seed)
+    spec = synth.GridSpec(rows=3, cols=4, tile_h=96, tile_w=160, ov_y=20, ov_x=36, seed=50 + seed)
+    shifts = placement.Shifts((int(rng.integers(-3, 4)), -36), (-20, int(rng.integers(-3, 4))))
+    rects = placement.grid_rects(3, 4, 160, 96, shifts)
+    wc, hc = placement.canvas_size(3, 4, 160, 96, use_registration=True, shifts=shifts)
+    n_planes = 7
+    tiles_np = np.stack([np.roll(spec.tile_stack(), 3 * p, axis=2) for p in range(n_planes)])
+    flat_np = synth.synthetic_flatfield(96, 160, np.float32)
+    arena = native.DeviceArena(64 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=128 * MiB)
+    arena.take(12345)                                          # the canvas does not start at the arena's base
+    guard = arena.take(arena.free_bytes - 4096, align=512)
+    guard.fill_(0xA5)
+    arena.reset()
+    arena.take(12345)
+    canvas = native.empty_canvas(n_planes, hc, wc, torch.uint16, dev, arena=arena)
+    assert canvas.data_ptr() % 128 == 0 and canvas.data_ptr() > arena.base
+    plan = native.FusePlan(rects, 96, 160, hc, wc)
+    flat = torch.from_numpy(flat_np).to(dev)
+    tiles = torch.from_numpy(tiles_np).to(dev)
+    native.fuse_planes(plan, tiles, canvas, [flat] * n_planes, flags=native.SQ_FUSE_FORCE_QUEUES)
+    torch.cuda.synchronize()
+    for p in range(n_planes):
+        want = O.fuse_plane_overwrite(list(tiles_np[p]), rects, hc, wc, flat_np)
+        np.testing.assert_array_equal(canvas[p].cpu().numpy(), want)
+    # the bytes between the planes (stride padding) and after the last plane still hold the guard pattern
+    stride_b = canvas.stride(0) * 2
+    raw = torch.as_tensor(native._RawDeviceMemory(arena, canvas.data_ptr(), stride_b * n_planes + 1024), device=dev)
+    for p in range(n_planes):
+        pad = raw[p * stride_b + hc * wc * 2:(p + 1) * stride_b]
+        assert bool((pad == 0xA5).all())
+    assert bool((raw[stride_b * n_planes:] == 0xA5).all())
+    del raw, canvas, guard
+    arena.close()

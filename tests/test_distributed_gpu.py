@@ -144,12 +144,12 @@ def test_one_plane_split_across_ranks_by_chunk_rows(tmp_path, world):
 # all-pairs registration sharded by pair: the gathered float64 table of N ranks == one rank's, bit for bit
 # ---------------------------------------------------------------------------------------------------------------
 def _pairs_state(root, scan_pattern, run=False):
-    """Shifts + pair table of ``--dynamic-registration`` on the acquisition at ``root`` in THIS process's world."""
+    """Shifts + pair table of ``--all-pairs-registration`` on the acquisition at ``root`` in THIS process's world."""
     from image_stitcher_amd.stitcher import Stitcher
     from image_stitcher_amd.stitcher_parameters import StitchingParameters
     from image_stitcher_amd import sharding
-    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, dynamic_registration=True,
-                                      scan_pattern=scan_pattern), normalization='phase')
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, scan_pattern=scan_pattern),
+                  normalization='phase', all_pairs_registration=True)
     st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
     rank, world = sharding.rank_and_world()
     st._pair_ranks = (rank, world) if world > 1 else None

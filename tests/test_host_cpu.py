@@ -426,3 +426,38 @@ def test_row_bands_and_plane_band_units():
     assert sorted((j[0], j[4], j[5]) for j in jobs) == [(0, 2, 0), (0, 2, 1), (1, 1, 0)]
     with pytest.raises(ValueError):
         omezarr.chunk_jobs(band, [(0, 0, 0)], (1, 1, 1, 512, 512), row_offset=1000, level_heights=[1100, 550])
+
+
+def test_dynamic_registration_is_stored_and_ignored_like_the_reference(tmp_path, monkeypatch):
+    """The reference parses --dynamic-registration, stores it (stitcher.py:92) and never reads it: with the flag set its
+    shifts are the centre-pair ones.  Same here -- on the golden acquisition whose centre tile is blank (where the
+    all-pairs median of this build WOULD differ) ``dynamic_registration=True`` ends with the reference's golden shifts and
+    never enters the all-pairs path; that path sits behind a flag of this build (--all-pairs-registration).  No GPU here:
+    the two pair registrations go through the oracle (the device versions are pinned by tests/test_stitcher_gpu.py)."""
+    from image_stitcher_amd import registration
+    from image_stitcher_amd.stitcher import Stitcher
+    info, _ = load_case('reg_blank_centre')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    monkeypatch.setattr(registration, 'check_crop_lengths', lambda *a, **k: None)     # asks the library; not under test
+    a = stitcher_cli.parse_args(['-i', root, '-r', '--dynamic-registration'])
+    assert a.dynamic_registration and not a.all_pairs_registration
+    st = Stitcher(stitcher_cli.create_params(a), normalization=None, all_pairs_registration=a.all_pairs_registration)
+    assert st.dynamic_registration is True and st.all_pairs_registration is False
+    st.calculate_horizontal_shift = lambda l, r, w: O.calculate_horizontal_shift(l, r, w, st.dtype, None)
+    st.calculate_vertical_shift = lambda t, b, w: O.calculate_vertical_shift(t, b, w, st.dtype, None)
+    st._calculate_shifts_all_pairs = lambda *a, **k: pytest.fail("dynamic_registration must not select all-pairs registration")
+    st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
+    st.calculate_shifts(st.timepoints[0], st.regions[0])
+    assert (list(st.h_shift), list(st.v_shift)) == (info['h_shift'], info['v_shift'])
+    # and the flag of this build does select it
+    b = stitcher_cli.parse_args(['-i', root, '-r', '--all-pairs-registration'])
+    st2 = Stitcher(stitcher_cli.create_params(b), normalization=None, all_pairs_registration=b.all_pairs_registration)
+    assert st2.all_pairs_registration and not st2.dynamic_registration
+    called = []
+    st2._calculate_shifts_all_pairs = lambda *a, **k: called.append(1)
+    st2.get_timepoints(); st2.extract_acquisition_parameters(); st2.get_pixel_size(); st2.parse_acquisition_metadata()
+    st2.calculate_shifts(st2.timepoints[0], st2.regions[0])
+    assert called == [1]
+    # without -r the extension is off whatever the flag says
+    assert not Stitcher(StitchingParameters(input_folder=root), all_pairs_registration=True).all_pairs_registration

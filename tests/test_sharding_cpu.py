@@ -236,6 +236,22 @@ def _pair_table_worker(rank, world, port, out_dir):
             R.register_pair_subset = real
         np.testing.assert_array_equal(table, np.array([[i + 0.5, -i, 0.001 * i] for i in range(len(pairs))]))
         assert seen['cells'] == R.cells_of_pairs(pairs, R.pairs_of_rank(len(pairs), rank, world)) and len(seen['cells']) < 20
+        # a rank of this N-rank group that registers a region ON ITS OWN (per-region all-pairs registration with
+        # the regions dealt to the ranks: Stitcher.run calls calculate_shifts without _pair_ranks, i.e. rank 0 of a world
+        # of 1) takes no part in a collective -- the other ranks are busy with THEIR regions -- and gets its own rows back.
+        # Every rank does it with a different table; a collective here would hang or mix them.
+        own = np.arange(21, dtype=np.float64).reshape(7, 3) + 100.0 * rank
+        np.testing.assert_array_equal(sh.all_gather_pair_table(own, 7, 0, 1), own)
+
+        def fake_all(tiles, local_index, prs, indices, h, w, mx, my, normalization='phase', minmax=None):
+            assert list(indices) == list(range(len(pairs)))          # the whole list: this rank alone registers its region
+            return np.array([[i + rank, -i, 0.5] for i in indices], dtype=np.float64).reshape(-1, 3)
+        R.register_pair_subset = fake_all
+        try:
+            alone = R.register_all_pairs_sharded(pairs, load_cells, 64, 64, 16, 16, 'phase', rank=0, world=1)
+        finally:
+            R.register_pair_subset = real
+        np.testing.assert_array_equal(alone, np.array([[i + rank, -i, 0.5] for i in range(len(pairs))]))
         open(os.path.join(out_dir, f'pairs_ok{rank}'), 'w').close()
     finally:
         dist.destroy_process_group()
@@ -416,3 +432,40 @@ def test_bench_committed_traffic_scales_with_the_planes_per_launch():
     assert abs(part - full * (25 / 3) / 10) < 1 and 'scaled to the 8.33333 planes' in src2
     assert bench.committed_traffic('cfg2', 1)[0] is None
     assert bench.committed_traffic('cfg3', 40)[0] > 1.5e11
+
+
+def test_bench_line_keys_for_the_scaling_curve(monkeypatch):
+    """every bench line names the strong-scaling point under ONE key pair (scale_workload / scale_value), the
+    job's parallelism text follows the registration mode that ran, and a world larger than the node's GPUs stops with one line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_test3', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # N = 1 region line: value is config 3, the curve's point comes from the job run afterwards on the same GPU
+    region = {'value': 1577000.0, 'unit': 'Mvoxel/s', 'headline_job_on_this_gpu': {
+        'workload': bench.WORKLOADS['cfg4']['desc'], 'value': 1552700.0, 'unit': 'Mvoxel/s', 'ms_per_step': 547.1, 'wall_ms_per_job': 910.0}}
+    out = bench.with_scale_keys(dict(region), region['headline_job_on_this_gpu'])
+    assert out['value'] == 1577000.0 and out['scale_value'] == 1552700.0 and out['scale_workload'] == bench.WORKLOADS['cfg4']['desc']
+    assert out['scale_ms_per_job'] == 547.1 and out['scale_wall_ms_per_job'] == 910.0 and out['scale_unit'] == 'Mvoxel/s'
+    # a job line (N ranks) is that point itself: same keys, same workload text as the N = 1 line's
+    job = bench.with_scale_keys({'value': 9.9e6, 'unit': 'Mvoxel/s'}, {'workload': bench.WORKLOADS['cfg4']['desc'], 'value': 9.9e6,
+                                                                       'unit': 'Mvoxel/s', 'ms_per_step': 85.0, 'wall_ms_per_job': 130.0})
+    assert job['scale_value'] == job['value'] and job['scale_workload'] == out['scale_workload']
+    # no job in the run: the keys are there and say null
+    none = bench.with_scale_keys({'value': 1.0, 'unit': 'Mvoxel/s'}, None)
+    assert none['scale_value'] is None and none['scale_workload'] is None and 'no headline job' in none['scale_note']
+    # parallelism text per registration mode
+    ap = bench.parallelism_text(8, 'nccl', True)
+    assert 'pair table all-gathered over RCCL' in ap and 'rank 0 registers' not in ap and '8 GPUs' in ap
+    cp = bench.parallelism_text(8, 'nccl', False)
+    assert 'rank 0 registers' in cp and '8-int32 shift row' in cp
+    assert 'gloo' in bench.parallelism_text(2, 'gloo', True) and '1 GPU ' in bench.parallelism_text(1, 'nccl', True)
+    # one rank per GPU
+    monkeypatch.delenv('SQ_DIST_BACKEND', raising=False)
+    bench.check_device_count(8, 8)
+    bench.check_device_count(1, 8)
+    with pytest.raises(SystemExit) as e:
+        bench.check_device_count(8, 1)
+    assert '--gpus 8' in str(e.value) and '1 GPU' in str(e.value)
+    monkeypatch.setenv('SQ_DIST_BACKEND', 'gloo')      # the rehearsal of N ranks on one card
+    bench.check_device_count(5, 1)

@@ -144,8 +144,9 @@ def test_run_fires_the_reference_signals(tmp_path):
     assert (list(st.h_shift), list(st.v_shift)) == (info['h_shift'], info['v_shift'])
 
 
-def test_dynamic_registration_all_pairs_survives_a_bad_centre_tile(tmp_path):
-    """--dynamic-registration (ignored by the reference) = all adjacent pairs, median.  With the centre
+def test_all_pairs_registration_survives_a_bad_centre_tile(tmp_path):
+    """--all-pairs-registration (an addition of this build) = all adjacent pairs, median; --dynamic-registration is
+    stored and ignored like in the reference (stitcher.py:92) and leaves the centre-pair result.  With the centre
     tile replaced by an empty field the centre-pair result is what the reference computes for a blank tile
     (golden case reg_blank_centre) -- wrong for the mosaic; the all-pairs median is still the planted drift.
     4 x 5 S-Pattern grid: the blank tile spoils 2 of the 8 pairs of its row group, a minority."""
@@ -155,9 +156,9 @@ def test_dynamic_registration_all_pairs_survives_a_bad_centre_tile(tmp_path):
     root = str(tmp_path / 'acq')
     synth.write_acquisition(spec, root)
 
-    def shifts(dynamic):
+    def shifts(all_pairs, dynamic=False):
         st = Stitcher(StitchingParameters(input_folder=root, use_registration=True, dynamic_registration=dynamic,
-                                          scan_pattern='S-Pattern'), normalization='phase')
+                                          scan_pattern='S-Pattern'), normalization='phase', all_pairs_registration=all_pairs)
         st.get_timepoints(); st.extract_acquisition_parameters(); st.get_pixel_size(); st.parse_acquisition_metadata()
         st.calculate_shifts(st.timepoints[0], st.regions[0])
         return tuple(st.h_shift), tuple(st.v_shift), tuple(st.h_shift_rev), int(st.h_shift_rev_odd)
@@ -172,7 +173,9 @@ def test_dynamic_registration_all_pairs_survives_a_bad_centre_tile(tmp_path):
     centre_fov = spec.fov_index(1, 2)
     path = os.path.join(root, '0', f'R0_{centre_fov}_0_{synth.channel_file_token(spec.channels[0])}.tiff')
     write_tiff(path, np.full((spec.tile_h, spec.tile_w), 1234, dtype=np.uint16))
-    assert shifts(False)[0] != centre[0]          # the reference's centre-pair scheme is derailed
+    derailed = shifts(False)
+    assert derailed[0] != centre[0]               # the reference's centre-pair scheme is derailed
+    assert shifts(False, dynamic=True) == derailed    # ... and its --dynamic-registration flag changes nothing, as in the reference
     after = shifts(True)                          # the all-pairs median is not (v_shift: two populations, see above)
     assert (after[0], after[2], after[3]) == (dyn[0], dyn[2], dyn[3]) and after[1][0] == dyn[1][0]
 

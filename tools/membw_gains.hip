@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <dlfcn.h>
 
 #define CK(x)                                                                                  \
     do {                                                                                       \
@@ -70,6 +72,16 @@ __device__ __forceinline__ uint32_t quot_pair(uint32_t word, float g0, float g1,
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
 __device__ __forceinline__ void st_nt(char *p, u32x4 v) { __builtin_nontemporal_store(v, (G1 u32x4 *)p); }
+// the same quotient on the PACKED float32 pipe: two pixels per v_pk_mul_f32 / v_pk_fma_f32 (IEEE per component: the same bits)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t quot_pair_pk(uint32_t word, f32x2 g, f32x2 r) {
+    const f32x2 n = {(float)(word & 0xFFFFu), (float)(word >> 16)};
+    f32x2 q = n * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-g, q, n), r, q);
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 p = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(q[0]), cvt_u32_sat(q[1]));
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+}
 
 struct RowAddr {
     const char *s;   // plane 0 source row
@@ -126,6 +138,52 @@ __global__ __launch_bounds__(256) void k_regs(const Geo P) {
                 if (GAINS) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) ov[c] = quot_pair(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                }
+                if (act) st_nt(A.d + z * P.dst_plane + o, ov);
+            }
+        }
+    }
+}
+
+// ---- A2: the shipped structure with the quotient on the packed float32 pipe --------------------------------------------------------------------------------
+template <int Z, bool GAINS>
+__global__ __launch_bounds__(256) void k_regs_pk(const Geo P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    for (int j = 0; j < 2; ++j) {
+        const int r = blk * 8 + wave + 4 * j;
+        if (r >= P.rows) break;
+        const RowAddr A = row_of(P, tile, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (64 * k - A.shift >= nvec) break;
+            const int i = lane + 64 * k - A.shift;
+            const bool act = i >= 0 && i < nvec;
+            const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+            float g[8], rc[8];
+            if (GAINS) {
+                const f32x4 a = ((const G1 F4U *)(A.g + o * 2u))->v, b = ((const G1 F4U *)(A.g + o * 2u + 16))->v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[e] = a[e];
+                    g[4 + e] = b[e];
+                }
+            }
+            u32x4 px[Z];
+#pragma unroll
+            for (int z = 0; z < Z; ++z) px[z] = ((const G1 U4U *)(A.s + z * P.src_plane + o))->v;
+            if (GAINS) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rc[c] = __builtin_amdgcn_rcpf(g[c]);
+            }
+#pragma unroll
+            for (int z = 0; z < Z; ++z) {
+                u32x4 ov = px[z];
+                if (GAINS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ov[c] = quot_pair_pk(px[z][c], f32x2{g[2 * c], g[2 * c + 1]}, f32x2{rc[2 * c], rc[2 * c + 1]});
                 }
                 if (act) st_nt(A.d + z * P.dst_plane + o, ov);
             }
@@ -317,7 +375,7 @@ __global__ __launch_bounds__(256) void k_fill_rows(const Geo P) {
 // per-plane canvas pointers (each plane its own allocation): the row fill and the plain 5-planes-per-thread copy
 struct PlanePtrs { char *d[ZMAX]; };
 template <int Z, bool COPY>
-__global__ __launch_bounds__(256) void k_rows_pp(const Geo P, const PlanePtrs D) {
+__device__ __forceinline__ void k_rows_pp_body(const Geo &P, const PlanePtrs &D) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nblk = (P.rows + 7) / 8;
     const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
@@ -341,6 +399,16 @@ __global__ __launch_bounds__(256) void k_rows_pp(const Geo P, const PlanePtrs D)
         }
     }
 }
+
+template <int Z, bool COPY>
+__global__ __launch_bounds__(256) void k_rows_pp(const Geo P, const PlanePtrs D) { k_rows_pp_body<Z, COPY>(P, D); }
+
+// ---- mode 500: the same row fill under three NAMES, so that per-dispatch PMC values can be told apart by kernel name ----
+__global__ __launch_bounds__(256) void k_pair_same_class(const Geo P, const PlanePtrs D) { k_rows_pp_body<2, false>(P, D); }
+__global__ __launch_bounds__(256) void k_pair_other_class(const Geo P, const PlanePtrs D) { k_rows_pp_body<2, false>(P, D); }
+__global__ __launch_bounds__(256) void k_single_plane(const Geo P, const PlanePtrs D) { k_rows_pp_body<1, false>(P, D); }
+__global__ __launch_bounds__(256) void k_pair_same_class_copy(const Geo P, const PlanePtrs D) { k_rows_pp_body<2, true>(P, D); }
+__global__ __launch_bounds__(256) void k_pair_other_class_copy(const Geo P, const PlanePtrs D) { k_rows_pp_body<2, true>(P, D); }
 
 // ---- the canvas' all-zero TAIL (the reference's oversize rows: 20 % of the voxels): a dense block of full-width rows ----
 // (a) cut like the plan cuts it today: items of 8 rows x 4096-byte pieces, wave w rows w and w + 4
@@ -460,9 +528,25 @@ int main(int argc, char **argv) {
     char *src, *dst, *ref;
     float *gain;
     unsigned long long *bad;
+    if (getenv("MEMBW_MIXED")) {
+        // dst and ref in a MIXED arena (libsquidstitch's sq_arena_create through its C ABI: physical slices classified and mapped
+        // round-robin over the card's memory classes) -- created FIRST, while the card is empty, so that it can choose
+        void *lib = dlopen(getenv("MEMBW_MIXED"), RTLD_NOW);
+        if (!lib) { printf("dlopen: %s\n", dlerror()); return 1; }
+        typedef void *(*create_t)(int64_t, int64_t, int64_t, int64_t, int32_t, void *, void *);
+        create_t create = (create_t)dlsym(lib, "sq_arena_create");
+        struct { void *base; int64_t bytes, slice; int32_t n_slices, n_cand, n_classes, cs[8], cc[8], inter; float probe_ms, create_ms, lo, hi; } info;
+        const size_t need = 2 * Z * P.dst_plane + (64 << 20);
+        if (!create || !create((int64_t)need, (int64_t)(3 * need), 0, 0, 0, nullptr, &info)) { printf("sq_arena_create failed\n"); return 1; }
+        printf("dst and ref in a mixed arena: %d slices of %ld MiB from %d candidates, %d classes (%d %d %d %d ...), created in %.0f ms\n", info.n_slices,
+               (long)(info.slice >> 20), info.n_cand, info.n_classes, info.cs[0], info.cs[1], info.cs[2], info.cs[3], info.create_ms);
+        dst = (char *)info.base;
+        ref = dst + Z * P.dst_plane;
+    } else {
+        CK(hipMalloc(&dst, Z * P.dst_plane));
+        CK(hipMalloc(&ref, Z * P.dst_plane));
+    }
     CK(hipMalloc(&src, Z * P.src_plane));
-    CK(hipMalloc(&dst, Z * P.dst_plane));
-    CK(hipMalloc(&ref, Z * P.dst_plane));
     CK(hipMalloc(&gain, (size_t)T * T * 4));
     CK(hipMalloc(&bad, 8));
     hipLaunchKernelGGL(k_init, dim3(4096), dim3(256), 0, 0, (uint32_t *)src, Z * P.src_plane / 4, 12345u);
@@ -492,6 +576,285 @@ int main(int argc, char **argv) {
         if (h) printf("!! %s: %s\n", what, buf);
         return buf;
     };
+    if (argc > 5 && atoi(argv[5]) == 700) {
+        // A MIXED ARENA: device memory taken in SLICE-sized physical pieces (hipMemCreate), classified UNIT by UNIT (a unit =
+        // 512 MiB of consecutively created slices: physical memory is handed out in long runs) by the pair fill, and the slices
+        // mapped into ONE virtual range round-robin over the classes (hipMemAddressReserve / hipMemMap): every plane laid out in
+        // that range then has all classes under it at SLICE granularity.  Compared in this process with the same kernels on a
+        // plain hipMalloc of the same size: single plane, 5 consecutive planes, kernel A, linear fill.
+        //   membw_gains reps 0 0 1 700 [GiB=96] [slice MiB=512] [order: 0 = round-robin, 1 = natural (control)]
+        const size_t gib = argc > 6 ? (size_t)atoll(argv[6]) : 96;
+        const size_t SLICE = (argc > 7 ? (size_t)atoll(argv[7]) : 512) << 20;
+        const int natural = argc > 8 ? atoi(argv[8]) : 0;
+        const size_t UNIT = SLICE > ((size_t)512 << 20) ? SLICE : ((size_t)512 << 20);
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        const int spu = (int)(UNIT / SLICE);
+        const int nu = (int)((gib << 30) / UNIT), n = nu * spu;
+        printf("mixed arena: %d slices of %zu MiB in %d units of %zu MiB (allocation granularity %zu KiB)\n", n, SLICE >> 20, nu, UNIT >> 20, gran >> 10);
+        hipMemGenericAllocationHandle_t *h = (hipMemGenericAllocationHandle_t *)malloc(sizeof(hipMemGenericAllocationHandle_t) * n);
+        int *order = (int *)malloc(sizeof(int) * n);
+        auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+        double t0 = now();
+        for (int i = 0; i < n; ++i) CK(hipMemCreate(&h[i], SLICE, &prop, 0));
+        double t1 = now();
+        char *va = nullptr;
+        CK(hipMemAddressReserve((void **)&va, (size_t)n * SLICE, (size_t)1 << 30, nullptr, 0));
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        for (int i = 0; i < n; ++i) CK(hipMemMap(va + (size_t)i * SLICE, SLICE, 0, h[i], 0));
+        double t2 = now();
+        CK(hipMemSetAccess(va, (size_t)n * SLICE, &acc, 1));
+        double t3 = now();
+        printf("host: hipMemCreate x %d %.1f ms, hipMemMap x %d %.1f ms, hipMemSetAccess %.1f ms\n", n, (t1 - t0) * 1e3, n, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
+        // a probe geometry that fits one unit
+        Geo Q = P;
+        Q.src = src;
+        Q.dst = nullptr;
+        for (Q.G = 16; Q.G > 1; --Q.G) {
+            Q.dst_pitch = (size_t)Q.G * Q.S + 560;
+            Q.dst_ty = (size_t)Q.rows * Q.dst_pitch;
+            if ((size_t)Q.G * Q.rows * Q.dst_pitch <= UNIT) break;
+        }
+        const unsigned qitems = (unsigned)(Q.G * Q.G * ((Q.rows + 7) / 8));
+        const double qmoved = (double)Q.G * Q.G * Q.rows * Q.S;      // bytes ONE plane's fill writes
+        printf("probe: %d x %d tiles, %.0f MB per unit\n", Q.G, Q.G, qmoved / 1e6);
+        int *cls = (int *)malloc(sizeof(int) * nu);
+        double *rt = (double *)malloc(sizeof(double) * nu);
+        for (int k = 0; k < nu; ++k) cls[k] = -1;
+        int ncls = 0;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0));
+        int probes = 0;
+        for (; ncls < 8; ++ncls) {
+            int ref = -1;
+            for (int k = 0; k < nu; ++k)
+                if (cls[k] < 0) { ref = k; break; }
+            if (ref < 0) break;
+            cls[ref] = ncls;
+            double lo = 1e9, hi = 0;
+            for (int k = 0; k < nu; ++k) {
+                if (cls[k] >= 0) continue;
+                PlanePtrs D{};
+                D.d[0] = va + (size_t)ref * UNIT;
+                D.d[1] = va + (size_t)k * UNIT;
+                const double ms2 = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<2, false>), dim3(qitems), dim3(256), 0, 0, Q, D); }, 2);
+                rt[k] = 2 * qmoved / ms2 / 1e6 / 8000;
+                lo = rt[k] < lo ? rt[k] : lo;
+                hi = rt[k] > hi ? rt[k] : hi;
+                ++probes;
+            }
+            int members = 1;
+            const double cut = hi - lo > 0.06 ? 0.5 * (lo + hi) : (ncls == 0 ? 1e9 : (lo < 0.62 ? 1e9 : -1));
+            for (int k = 0; k < nu; ++k)
+                if (cls[k] < 0 && rt[k] < cut) { cls[k] = ncls; ++members; }
+            printf("class %c: reference unit %d, pair rates %.3f .. %.3f, %d units\n", 'A' + ncls, ref, lo, hi, members);
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float pms;
+        CK(hipEventElapsedTime(&pms, e0, e1));
+        printf("%d probes, %.1f ms on the device\nunits in allocation order: ", probes, pms);
+        for (int k = 0; k < nu; ++k) printf("%c", cls[k] >= 0 ? 'A' + cls[k] : '?');
+        printf("\n");
+        // remap round-robin over the classes, slice by slice
+        CK(hipDeviceSynchronize());
+        t0 = now();
+        CK(hipMemUnmap(va, (size_t)n * SLICE));
+        int no = 0;
+        if (natural) {
+            for (int i = 0; i < n; ++i) order[no++] = i;
+        } else {
+            int next[8] = {};
+            bool any = true;
+            while (any) {
+                any = false;
+                for (int c = 0; c < ncls; ++c) {
+                    while (next[c] < n && cls[next[c] / spu] != c) ++next[c];
+                    if (next[c] < n) { order[no++] = next[c]++; any = true; }
+                }
+            }
+        }
+        for (int i = 0; i < no; ++i) CK(hipMemMap(va + (size_t)i * SLICE, SLICE, 0, h[order[i]], 0));
+        CK(hipMemSetAccess(va, (size_t)no * SLICE, &acc, 1));
+        printf("remapped %s in %.1f ms; first slices: ", natural ? "in NATURAL order (control)" : "round-robin over the classes", (now() - t0) * 1e3);
+        for (int i = 0; i < no && i < 96; ++i) printf("%c", 'A' + cls[order[i] / spu]);
+        printf("\n");
+        // the plain arena of the same size
+        char *plain;
+        CK(hipMalloc(&plain, (size_t)n * SLICE));
+        const double moved1 = moved / Z;
+        auto bench = [&](const char *name, char *base) {
+            P.src = src;
+            for (int round = 0; round < 2; ++round) {
+                // single planes at a few offsets, 5 consecutive planes at a few offsets
+                printf("%s round %d: single plane fill", name, round);
+                for (size_t off : {(size_t)0, (size_t)11 << 30, (size_t)37 << 30, (size_t)61 << 30}) {
+                    if (off + P.dst_plane > (size_t)n * SLICE) continue;
+                    PlanePtrs D{};
+                    D.d[0] = base + off;
+                    P.dst = nullptr;
+                    const double ms = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<1, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+                    printf(" %.3f", 0.5 * moved1 / ms / 1e6 / 8000);
+                }
+                printf(" | 5 consecutive planes: fill / copy / kernel A");
+                for (size_t off : {(size_t)0, (size_t)23 << 30, (size_t)52 << 30}) {
+                    if (off + Z * P.dst_plane > (size_t)n * SLICE) continue;
+                    PlanePtrs D{};
+                    for (int z = 0; z < Z; ++z) D.d[z] = base + off + z * P.dst_plane;
+                    P.dst = nullptr;
+                    const double msr = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, false>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+                    const double msc = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<Z, true>), dim3(items8), dim3(256), 0, 0, P, D); }, reps);
+                    P.dst = base + off;
+                    const double msa = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+                    printf("  %.3f / %.3f / %.3f", 0.5 * moved / msr / 1e6 / 8000, moved / msc / 1e6 / 8000, moved / msa / 1e6 / 8000);
+                }
+                const size_t nlin = (size_t)8 << 30 >> 4;
+                const double msf = time_ms([&] { hipLaunchKernelGGL(k_linear_fill, dim3((unsigned)((nlin + 255) / 256)), dim3(256), 0, 0, (u32x4 *)base, nlin); }, reps);
+                const double msl = time_ms([&] { hipLaunchKernelGGL(k_linear_copy, dim3((unsigned)((nlin + 255) / 256)), dim3(256), 0, 0, (const u32x4 *)src, (u32x4 *)base, nlin); }, reps);
+                printf(" | linear fill / copy of 8 GiB %.3f / %.3f\n", (double)nlin * 16 / msf / 1e6 / 8000, 2.0 * nlin * 16 / msl / 1e6 / 8000);
+                fflush(stdout);
+            }
+        };
+        bench("plain hipMalloc", plain);
+        bench("mixed arena    ", va);
+        bench("plain hipMalloc", plain);
+        bench("mixed arena    ", va);
+        // the SOURCE in mixed memory too: kernel A reading its tiles from the mixed arena (upper half) and writing the lower half
+        if ((size_t)n * SLICE >= Z * (P.src_plane + P.dst_plane) + ((size_t)2 << 30)) {
+            char *msrc = va + (((Z * P.dst_plane) + ((size_t)1 << 30)) & ~(((size_t)1 << 30) - 1));
+            CK(hipMemcpy(msrc, src, Z * P.src_plane, hipMemcpyDeviceToDevice));
+            for (int round = 0; round < 2; ++round) {
+                P.src = msrc;
+                P.dst = va;
+                const double m1 = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+                P.src = src;
+                const double m2 = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+                printf("kernel A, canvas in the mixed arena: tiles in the mixed arena too %.3f | tiles in a plain hipMalloc %.3f\n", moved / m1 / 1e6 / 8000, moved / m2 / 1e6 / 8000);
+            }
+        }
+        return 0;
+    }
+    if (argc > 5 && atoi(argv[5]) == 600) {
+        // HOW MANY CLASSES, HOW BIG: as much device memory as one allocation gives, plane k at +k GiB, every plane classified
+        // against reference planes: class 0 = what collides with plane 0 (the pair fills at one plane's rate), class 1 = what
+        // collides with the first plane outside class 0, and so on.  Prints the class of every GiB and the GiB per class.
+        P.src = src;
+        P.dst = nullptr;
+        size_t gib = argc > 6 ? (size_t)atoll(argv[6]) : 240;
+        char *big = nullptr;
+        while (gib >= 32 && hipMalloc(&big, gib << 30) != hipSuccess) { (void)hipGetLastError(); gib -= 8; }
+        if (!big) { printf("no big allocation\n"); return 1; }
+        const size_t STEP = (size_t)1 << 30;
+        const int nk = (int)(((gib << 30) - P.dst_plane) / STEP);
+        const double moved1 = moved / Z;
+        printf("one allocation of %zu GiB at %p; plane k at +k GiB (a plane is %.2f GiB)\n", gib, (void *)big, P.dst_plane / 1073741824.0);
+        static int cls[512];
+        for (int k = 0; k < nk; ++k) cls[k] = -1;
+        int ncls = 0;
+        for (;;) {
+            int ref = -1;
+            for (int k = 0; k < nk; ++k)
+                if (cls[k] < 0) { ref = k; break; }
+            if (ref < 0 || ncls >= 12) break;
+            cls[ref] = ncls;
+            if (ref + 1 < nk && cls[ref + 1] < 0) cls[ref + 1] = -2;   // overlaps the reference plane: decided by its neighbours below
+            int members = 1;
+            for (int k = 0; k < nk; ++k) {
+                if (cls[k] != -1) continue;
+                if (abs(k - ref) < 2) continue;
+                PlanePtrs D{};
+                D.d[0] = big + ref * STEP;
+                D.d[1] = big + k * STEP;
+                const double ms2 = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<2, false>), dim3(items8), dim3(256), 0, 0, P, D); }, 2);
+                const double r = moved1 / ms2 / 1e6 / 8000;
+                if (r < 0.64) { cls[k] = ncls; ++members; }
+            }
+            printf("class %d: reference plane at +%d GiB, %d planes collide with it\n", ncls, ref, members);
+            fflush(stdout);
+            ++ncls;
+        }
+        for (int k = 0; k < nk; ++k)
+            if (cls[k] == -2) cls[k] = k + 1 < nk && cls[k + 1] >= 0 ? cls[k + 1] : cls[k - 1];
+        int size[16] = {};
+        printf("class of every GiB:");
+        for (int k = 0; k < nk; ++k) {
+            if (k % 64 == 0) printf("\n  +%3d GiB: ", k);
+            printf("%c", cls[k] >= 0 ? 'A' + cls[k] : '?');
+            if (cls[k] >= 0) ++size[cls[k]];
+        }
+        printf("\nGiB per class:");
+        for (int c = 0; c < ncls; ++c) printf(" %c %d", 'A' + c, size[c]);
+        printf("\n");
+        // cross-check: one plane from each of the first three classes, pairwise and all together
+        return 0;
+    }
+    if (argc > 5 && atoi(argv[5]) == 500) {
+        // CLASSES UNDER THE COUNTERS: one big allocation, plane k at +k GiB.  (1) row fill of the pair (0, k) for every k: which
+        // stretches collide with the stretch at 0 ("same class": the pair runs at one plane's rate) and which do not;
+        // (2) the same fill launched under three kernel NAMES -- k_pair_same_class, k_pair_other_class, k_single_plane -- a few
+        // times each, so that a rocprofv3 --pmc pass of this very process reports the memory-side counters per case.
+        P.src = src;
+        P.dst = nullptr;
+        const size_t gib = argc > 6 ? (size_t)atoll(argv[6]) : 128;
+        const size_t total = gib << 30, STEP = (size_t)1 << 30;
+        char *big;
+        CK(hipMalloc(&big, total));
+        const int nk = (int)((total - P.dst_plane) / STEP);
+        const double moved1 = moved / Z;
+        printf("one allocation of %zu GiB at %p; plane k at +k GiB (a plane is %.2f GiB); row fill of the pair (0, k), fraction of 8 TB/s\n",
+               total >> 30, (void *)big, P.dst_plane / 1073741824.0);
+        static double rate[512];
+        double lo = 1e9, hi = 0;
+        for (int k = 2; k < nk; ++k) {
+            PlanePtrs D{};
+            D.d[0] = big;
+            D.d[1] = big + k * STEP;
+            const double ms2 = time_ms([&] { hipLaunchKernelGGL((k_rows_pp<2, false>), dim3(items8), dim3(256), 0, 0, P, D); }, 2);
+            rate[k] = 0.5 * 2 * moved1 / ms2 / 1e6 / 8000;
+            lo = rate[k] < lo ? rate[k] : lo;
+            hi = rate[k] > hi ? rate[k] : hi;
+            printf(" %.3f", rate[k]);
+            if (k % 16 == 1) printf("\n");
+        }
+        printf("\n");
+        const double mid = 0.5 * (lo + hi);
+        // a "same class" k and an "other class" k, each with like neighbours (inside a stretch, not at its edge)
+        int ks = -1, kf = -1;
+        for (int k = 3; k + 1 < nk; ++k) {
+            const bool s = rate[k - 1] < mid && rate[k] < mid && rate[k + 1] < mid, f = rate[k - 1] > mid && rate[k] > mid && rate[k + 1] > mid;
+            if (s && ks < 0) ks = k;
+            if (f && kf < 0) kf = k;
+        }
+        printf("lowest %.3f, highest %.3f; same-class plane at +%d GiB, other-class plane at +%d GiB\n", lo, hi, ks, kf);
+        if (ks < 0 || kf < 0 || hi - lo < 0.08) {
+            printf("no two classes inside this allocation (spread %.3f): nothing to compare\n", hi - lo);
+            return 0;
+        }
+        PlanePtrs S{}, F{}, O{};
+        S.d[0] = F.d[0] = O.d[0] = big;
+        S.d[1] = big + ks * STEP;
+        F.d[1] = big + kf * STEP;
+        for (int round = 0; round < 3; ++round) {
+            const double a = time_ms([&] { hipLaunchKernelGGL(k_pair_same_class, dim3(items8), dim3(256), 0, 0, P, S); }, reps);
+            const double b = time_ms([&] { hipLaunchKernelGGL(k_pair_other_class, dim3(items8), dim3(256), 0, 0, P, F); }, reps);
+            const double c = time_ms([&] { hipLaunchKernelGGL(k_single_plane, dim3(items8), dim3(256), 0, 0, P, O); }, reps);
+            const double d = time_ms([&] { hipLaunchKernelGGL(k_pair_same_class_copy, dim3(items8), dim3(256), 0, 0, P, S); }, reps);
+            const double e = time_ms([&] { hipLaunchKernelGGL(k_pair_other_class_copy, dim3(items8), dim3(256), 0, 0, P, F); }, reps);
+            printf("round %d: fill pair same class %.3f ms = %.3f | pair other class %.3f ms = %.3f | single plane %.3f ms = %.3f | copy pair same %.3f ms = %.3f | copy pair other %.3f ms = %.3f of 8 TB/s\n",
+                   round, a, moved1 / a / 1e6 / 8000, b, moved1 / b / 1e6 / 8000, c, 0.5 * moved1 / c / 1e6 / 8000, d, 2 * moved1 / d / 1e6 / 8000, e,
+                   2 * moved1 / e / 1e6 / 8000);
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (argc > 5 && atoi(argv[5]) == 400) {
         // THE ZERO TAIL: 5 planes 16 GiB apart in one allocation (the arena's spacing), each with a dense tail of 15 128
         // rows x 116 068 bytes (the headline grid's); the three ways of writing it
@@ -716,6 +1079,9 @@ int main(int argc, char **argv) {
         CK(hipMemset(dst, 0, Z * P.dst_plane));
         ms = time_ms([&] { hipLaunchKernelGGL((k_regs<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
         report("A  regs: gains + reciprocals in VGPRs, 5 planes per thread (shipped structure)", ms, check("A"));
+        CK(hipMemset(dst, 0, Z * P.dst_plane));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_regs_pk<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("A2 regs, quotient on the packed float32 pipe (v_pk_mul_f32 / v_pk_fma_f32)", ms, check("A2"));
 #define RUN_B(ROWS)                                                                                                       \
     do {                                                                                                                  \
         CK(hipMemset(dst, 0, Z *P.dst_plane));                                                                            \
