@@ -97,6 +97,14 @@ def main():
     ap.add_argument('--host-plan', action='store_true',
                     help="headline job: build the whole fusion plan on the host and upload it (round 2) instead of expanding the "
                          "spans into the work list on the device")
+    ap.add_argument('--fusion-mode', choices=['overwrite', 'feather'], default='overwrite',
+                    help="region workloads: 'feather' adds the distance-weighted blend (the north star's fusion; an extension, parity "
+                         "against this build's own definition oracle.fuse_plane_feather) as a `feather` object to the line: the same "
+                         "planes, tiles and gains fused by fuse_feather_zg_kernel into the uint16 canvas and into a float32 one, "
+                         "2 rho + 2 (+ 2) bytes per voxel, HIP-event launch times, windows of one plane per channel compared with "
+                         "the oracle.  The default N = 1 run includes it (--no-feather skips it); `value` stays the overwrite "
+                         "fusion, the reference's own")
+    ap.add_argument('--no-feather', action='store_true')
     ap.add_argument('--weak', action='store_true', help='N > 1 with a region workload: one region per rank (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sha-out', default=None,
@@ -617,6 +625,11 @@ def run_region(ctx):
         out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas_of_plane)
         out['cpu_baseline_reference'] = REFERENCE_TIMING
         out['parity'].update(check)
+    want_feather = args.fusion_mode == 'feather' or (world == 1 and args.workload is None and not args.planes and not args.no_feather
+                                                     and not os.environ.get('SQ_BENCH_PMC_CHILD'))
+    if want_feather and rank == 0:
+        out['feather'] = feather_leg(args, dev, g, hc, wc, n_planes, order, order_rc, state['shifts'], tiles, canvas, canvas_of_plane,
+                                     plane_of_slot, ptrs, flat_list, slot_flats, flat_ptrs, check=not args.no_cpu_baseline)
     if world == 1 and args.workload is None and not args.planes and not os.environ.get('SQ_BENCH_NO_REFERENCE_JOB'):
         # The N > 1 runs of this script measure the headline job (cfg4, strong scaling).  For the record, the SAME job on
         # this one GPU (one step after one warm-up, ~3 s): the single-GPU point of that scaling curve, next to the config-3
@@ -639,6 +652,105 @@ def run_region(ctx):
             'launch_ms': job['roofline']['launch_ms'], 'host_ms_per_job': job['host_ms_per_job_rank0'],
             'registration': job['config']['registration']}
     return with_scale_keys(out, out.get('headline_job_on_this_gpu'))
+
+
+def feather_window_rects(rects, y0, y1, x0, x1):
+    """The rectangles cut to the canvas window [y0, y1) x [x0, x1), in the window's coordinates (geometry only: a rectangle's
+    source origin moves with the cut, so the tile pixels and their feather weights stay the ones of the whole canvas)."""
+    out = []
+    for sy, sx, h, w, dy, dx in np.asarray(rects, dtype=np.int64):
+        ya, yb, xa, xb = max(dy, y0), min(dy + h, y1), max(dx, x0), min(dx + w, x1)
+        out.append((sy + ya - dy, sx + xa - dx, max(0, yb - ya), max(0, xb - xa), max(0, ya - y0), max(0, xa - x0)))
+    return np.array(out, dtype=np.int64)
+
+
+def feather_leg(args, dev, g, hc, wc, n_planes, order, order_rc, shifts, tiles, canvas, canvas_of_plane, plane_of_slot, ptrs, flat_list,
+                slot_flats, flat_ptrs, check=True):
+    """The distance-weighted blend on the resident planes of the region workload: `fuse_feather_zg_kernel` into the uint16
+    canvas (with the workload's gains), then into a float32 canvas of half the planes (the arena's bytes).  Algorithmic
+    bytes: 2 rho per voxel read (rho = tile pixels / canvas voxels: every tile pixel once) + the voxel written
+    (+ the gain image once per plane).  Parity: canvas windows of one plane per channel -- a band over a tile-row seam with
+    its four-tile corners, and the canvas' top-left corner -- against oracle.fuse_plane_feather, this build's own definition
+    of the blend (the reference has none: PARITY UNPINNED): uint16 voxels equal, float32 voxels within 1e-5 relative."""
+    import torch
+    from image_stitcher_amd import native, placement
+    rects = placement.grid_rects(g, g, TILE, TILE, shifts, order=order_rc, crop=False)
+    plan = native.FusePlan(rects, TILE, TILE, hc, wc, native.SQ_FUSE_FEATHER)
+    rho = g * g * TILE * TILE / (hc * wc)
+    steps = max(3, min(args.steps, 10))
+
+    def timed(cv, n, flats, fp):
+        ms = []
+        for k in range(2 + steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            native.fuse_planes(plan, None, cv, flats, tile_ptrs=ptrs[:n * g * g], flat_ptrs=fp)
+            e1.record()
+            torch.cuda.synchronize()
+            if k >= 2:
+                ms.append(e0.elapsed_time(e1))
+        return float(np.mean(ms))
+
+    def entry(ms, n, out_bytes, flat):
+        alg = n * (hc * wc * (2 * rho + out_bytes) + (TILE * TILE * 4 if flat else 0))
+        return {'launch_ms': round(ms, 4), 'planes': n, 'bytes_per_voxel': round(2 * rho + out_bytes, 4), 'algorithmic_bytes_per_launch': int(alg),
+                'achieved': round(alg / ms / 1e6, 1), 'unit': 'GB/s', 'frac': round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                'value': round(n * hc * wc / ms / 1e3, 1), 'value_unit': 'Mvoxel/s'}
+
+    def compare(cv_of_plane, out_dtype, flat):
+        """Windows of one plane per channel (z 0) against the oracle's definition."""
+        from oracle import stitch_oracle as O
+        step = TILE - OVERLAP
+        windows = [(7 * step - 40, 7 * step + OVERLAP + 120, 0, wc), (0, 2300, 0, 2300)]
+        per = max(1, n_planes // max(1, len({id(f) for f in flat_list}) if flat_list else 1))
+        planes = sorted({c * per for c in range(max(1, n_planes // per))})[:4]
+        worst, bad, voxels = 0.0, 0, 0
+        t0 = time.perf_counter()
+        for p in planes:
+            if p not in cv_of_plane:
+                continue
+            host_tiles = [tiles[p, i].cpu().numpy() for i in order]
+            fl = flat_list[p].cpu().numpy() if (flat and flat_list) else None
+            for y0, y1, x0, x1 in windows:
+                y1, x1 = min(y1, hc), min(x1, wc)
+                want = O.fuse_plane_feather(host_tiles, feather_window_rects(rects, y0, y1, x0, x1), y1 - y0, x1 - x0, fl, out_dtype)
+                got = cv_of_plane[p][y0:y1, x0:x1].cpu().numpy()
+                voxels += want.size
+                if np.issubdtype(np.dtype(out_dtype), np.integer):
+                    bad += int(np.count_nonzero(got != want))
+                else:
+                    with np.errstate(all='ignore'):
+                        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30)
+                    rel[(got == want)] = 0.0
+                    worst = max(worst, float(np.nanmax(rel)))
+                    bad += int(np.count_nonzero(rel > 1e-5))
+        return {'planes': planes, 'windows': [list(w) for w in windows], 'voxels': voxels, 'mismatched_voxels': bad,
+                'max_rel_err': worst if not np.issubdtype(np.dtype(out_dtype), np.integer) else (0.0 if bad == 0 else None),
+                'oracle_s': round(time.perf_counter() - t0, 1)}
+
+    out = {'definition': "oracle.fuse_plane_feather (this build's own: the reference has no blend) -- PARITY UNPINNED",
+           'kernel': 'fuse_feather_zg_kernel (plane groups; one-tile items through the pipelined row copy / divide, two-tile strips through '
+                     'the grouped blend, corners plane by plane)',
+           'rho': round(rho, 4), 'plan_items': int(plan.n_items), 'steps': steps}
+    flat = bool(slot_flats)
+    out['u16'] = entry(timed(canvas, n_planes, slot_flats, flat_ptrs), n_planes, 2, flat)
+    out['u16']['canvas'] = 'uint16 (rounded half to even, clipped)' + (', float32 gains' if flat else '')
+    if check:
+        out['u16']['parity'] = compare({p: canvas_of_plane[p] for p in range(n_planes)}, np.uint16, flat)
+    if ARENAS and n_planes >= 2:
+        # the float32 canvas of half the planes in the same arena bytes (the uint16 canvas is done with)
+        nf = n_planes // 2
+        arena = ARENAS[-1]
+        arena.reset()
+        cf = native.empty_canvas(nf, hc, wc, torch.float32, dev, arena=arena)
+        fpf = native.pointer_table(slot_flats[:nf], dev) if flat else None
+        out['f32'] = entry(timed(cf, nf, slot_flats[:nf] if flat else None, fpf), nf, 4, flat)
+        out['f32']['canvas'] = 'float32 (the blended value as it is)' + (', float32 gains' if flat else '')
+        if check:
+            out['f32']['parity'] = compare({plane_of_slot[s]: cf[s] for s in range(nf)}, np.float32, flat)
+            out['f32']['parity']['tolerance'] = 'fused float voxels within 1e-5 relative (BASELINE.json north_star)'
+        del cf
+    return out
 
 
 def shift_parity(sh, truth):

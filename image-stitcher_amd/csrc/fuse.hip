@@ -39,6 +39,10 @@ struct __attribute__((packed)) U32x4U {  // 16 bytes at any alignment
 struct __attribute__((packed)) F32x4U {
     f32x4 v;
 };
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed)) U32x2U {  // 8 bytes at any alignment
+    u32x2 v;
+};
 struct __attribute__((packed)) F64x2U {
     f64x2 v;
 };
@@ -789,8 +793,30 @@ __device__ __forceinline__ double quot_of(double n, double g, double r) {
     const double q = n * r;
     return fma(fma(-g, q, n), r, q);
 }
+// Two float32 lanes per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: IEEE per component, so every bit is the scalar
+// form's).  The overwrite quotient (RND = 0: 3 of its 5.8 instructions per pixel) measured no faster packed, twice (round 1 on the
+// per-plane kernel, round 4 on the grouped structure in a mixed arena: tools/membw_gains "A2", 0.712 against 0.713) -- that path
+// waits on memory.  The feather paths do 8.5 (one tile, rounded) to 27 (two-tile strips) instructions per pixel: there it pays.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// div_u16_normal_ieee / div_by_refined on two lanes: n / d correctly rounded, r = the refined reciprocal of d
+__device__ __forceinline__ f32x2 div_by_refined2(f32x2 n, f32x2 d, f32x2 r) {
+    f32x2 q = n * r;
+    q = pk_fma(pk_fma(-d, q, n), r, q);
+    return pk_fma(pk_fma(-d, q, n), r, q);
+}
+#ifndef SQ_FEATHER_PACKED
+#define SQ_FEATHER_PACKED 1
+#endif
 template <int RND, typename G>
 __device__ __forceinline__ uint32_t quot_pair(uint32_t word, G g_lo, G g_hi, G r_lo, G r_hi) {
+    if constexpr (RND == 1 && std::is_same<G, float>::value && SQ_FEATHER_PACKED) {
+        const f32x2 n = {(float)(word & 0xFFFFu), (float)(word >> 16)};
+        const f32x2 q = div_by_refined2(n, f32x2{g_lo, g_hi}, f32x2{r_lo, r_hi});
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 p = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(__builtin_rintf(q[0])), cvt_u32_sat(__builtin_rintf(q[1])));
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+    }
     const G n0 = (G)(word & 0xFFFFu), n1 = (G)(word >> 16);
     const uint32_t a = cvt_u32_sat(quot_of<RND>(n0, g_lo, r_lo));
     const uint32_t b = cvt_u32_sat(quot_of<RND>(n1, g_hi, r_hi));
@@ -1385,12 +1411,19 @@ __device__ __forceinline__ float div_by_refined(float n, float d, float r) {   /
     return fmaf(fmaf(-d, q, n), r, q);
 }
 
-// OutT = uint16_t (round, clip, pack) or float (the blended value as it is: two 16-byte stores per 8 voxels)
-template <int FLAT, bool FULL, typename OutT = uint16_t>
+// OutT = uint16_t (round, clip, pack) or float (the blended value as it is: two 16-byte stores per 8 voxels).
+// NREF = 2: a strip two tiles cover.  NREF = 1 / 0 (float canvases only): a voxel ONE tile covers (its value, divided by its
+// gain) / none (zero) -- the uint16 canvas sends those through process_item_zg's pipelined rows, which write the tile dtype.
+// A float32 canvas is held to the north star's tolerance for fused float voxels, 1e-5 relative, not to the bits of the
+// definition: its quotients are n * r and acc * r with r the reciprocal after one Newton step (each within 2^-22 of the
+// correctly rounded quotient) instead of the five-instruction exact sequence -- 3 instructions per blended voxel instead of
+// 15.  Integer canvases stay bit-equal to the definition (rounding half to even hangs on the exact quotient).
+template <int FLAT, bool FULL, typename OutT = uint16_t, int NREF = 2>
 __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it, const int tid) {
     typedef uint16_t T;
     constexpr int VEC = 8;
     constexpr bool F32OUT = sizeof(OutT) == 4;
+    static_assert(NREF == 2 || F32OUT, "one-tile and empty items of an integer canvas take process_item_zg");
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
     OutT *cplane[ZB];
     const T *t0[ZB], *t1[ZB];
@@ -1404,9 +1437,27 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
     // FLAT = 2: float64 gains, which feather mode takes as float32 (the per-plane blend casts every gain it loads: the
     // arithmetic is float32 in either case) -- loaded as doubles here, cast once per 8-pixel group
     typedef typename std::conditional<FLAT == 2, double, float>::type GM;
-    const GM *flat = FLAT ? static_cast<const GM *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
+    const GM *flat = (FLAT && NREF) ? static_cast<const GM *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
     const int ya = sgpr(A.first.b), xa = sgpr(A.first.c), yb = sgpr(A.seam.b), xb = sgpr(A.seam.c);
     const int G = n / VEC + 1;   // upper bound of the whole groups of a row
+    auto load_gain8 = [&](int y, int x, f32x2 (&g)[4]) {
+        if constexpr (FLAT == 1) {
+            const float *gp = reinterpret_cast<const float *>(flat) + (int64_t)y * P.tile_w + x;
+            const f32x4 a = ldg<F32x4U>(gp), b = ldg<F32x4U>(gp + 4);
+            g[0] = f32x2{a[0], a[1]}, g[1] = f32x2{a[2], a[3]}, g[2] = f32x2{b[0], b[1]}, g[3] = f32x2{b[2], b[3]};
+        } else if constexpr (FLAT == 2) {
+            const double *gp = reinterpret_cast<const double *>(flat) + (int64_t)y * P.tile_w + x;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f64x2 a = ldg<F64x2U>(gp + 2 * h);
+                g[h] = f32x2{(float)a[0], (float)a[1]};
+            }
+        }
+    };
+    auto refined = [](f32x2 d) {      // recip_for<1> on two lanes (v_rcp_f32 has no packed form)
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return pk_fma(pk_fma(-d, r, f32x2{1.0f, 1.0f}), r, r);
+    };
     for (int idx = tid; idx < rows * G; idx += 256) {
         const int r = idx / G, j = idx - r * G;
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
@@ -1415,64 +1466,79 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
         const int v = (mis ? 1 : 0) + j;
         if (v >= (n + mis) / VEC) continue;
         const int p0 = v * VEC - mis;
+        if constexpr (NREF == 0) {      // uncovered canvas: zeros (float canvases; da.zeros, stitcher.py:362)
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) {
+                    stg_nt(cplane[z] + doff + p0, zero);
+                    stg_nt(cplane[z] + doff + p0 + 4, zero);
+                }
+            continue;
+        }
         const int y0 = ya + r, x0 = xa + p0, y1 = yb + r, x1 = xb + p0;
         const int64_t s0 = (int64_t)y0 * P.tile_pitch + x0, s1 = (int64_t)y1 * P.tile_pitch + x1;
-        f32x4 ga0{}, ga1{}, gb0{}, gb1{};
-        if constexpr (FLAT == 1) {
-            const float *gp0 = flat + (int64_t)y0 * P.tile_w + x0, *gp1 = flat + (int64_t)y1 * P.tile_w + x1;
-            ga0 = ldg<F32x4U>(gp0), ga1 = ldg<F32x4U>(gp0 + 4), gb0 = ldg<F32x4U>(gp1), gb1 = ldg<F32x4U>(gp1 + 4);
-        } else if constexpr (FLAT == 2) {
-            const double *gp0 = flat + (int64_t)y0 * P.tile_w + x0, *gp1 = flat + (int64_t)y1 * P.tile_w + x1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f64x2 a0 = ldg<F64x2U>(gp0 + 2 * h), a1 = ldg<F64x2U>(gp0 + 4 + 2 * h);
-                const f64x2 b0 = ldg<F64x2U>(gp1 + 2 * h), b1 = ldg<F64x2U>(gp1 + 4 + 2 * h);
-                ga0[2 * h] = (float)a0[0], ga0[2 * h + 1] = (float)a0[1], ga1[2 * h] = (float)a1[0], ga1[2 * h + 1] = (float)a1[1];
-                gb0[2 * h] = (float)b0[0], gb0[2 * h + 1] = (float)b0[1], gb1[2 * h] = (float)b1[0], gb1[2 * h + 1] = (float)b1[1];
-            }
+        f32x2 g0[4], g1[4];
+        if constexpr (FLAT != 0) {
+            load_gain8(y0, x0, g0);
+            if constexpr (NREF == 2) load_gain8(y1, x1, g1);
         }
         u32x4 ra[ZB], rb[ZB];
 #pragma unroll
         for (int z = 0; z < ZB; ++z)
             if (FULL || z < gn) {
                 ra[z] = ldg<U32x4U>(t0[z] + s0);
-                rb[z] = ldg<U32x4U>(t1[z] + s1);
+                if constexpr (NREF == 2) rb[z] = ldg<U32x4U>(t1[z] + s1);
             }
-        float g0[VEC], g1[VEC], r0[VEC], r1[VEC], w0[VEC], w1[VEC], ws[VEC], rw[VEC];
+        f32x2 r0[4], r1[4], w0[4], w1[4], ws[4], rw[4];
         const int wy0 = min(y0 + 1, P.tile_h - y0), wy1 = min(y1 + 1, P.tile_h - y1);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            if (FLAT) {
-                g0[e] = e < 4 ? ga0[e & 3] : ga1[e & 3];
-                g1[e] = e < 4 ? gb0[e & 3] : gb1[e & 3];
-                r0[e] = recip_for<1>(g0[e]);
-                r1[e] = recip_for<1>(g1[e]);
+        for (int h = 0; h < 4; ++h) {
+            if constexpr (FLAT != 0) {
+                r0[h] = refined(g0[h]);
+                if constexpr (NREF == 2) r1[h] = refined(g1[h]);
             }
-            w0[e] = (float)min(min(x0 + e + 1, P.tile_w - (x0 + e)), wy0);
-            w1[e] = (float)min(min(x1 + e + 1, P.tile_w - (x1 + e)), wy1);
-            ws[e] = __fadd_rn(w0[e], w1[e]);
-            rw[e] = recip_for<1>(ws[e]);
+            if constexpr (NREF == 2) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int e = 2 * h + c;
+                    w0[h][c] = (float)min(min(x0 + e + 1, P.tile_w - (x0 + e)), wy0);
+                    w1[h][c] = (float)min(min(x1 + e + 1, P.tile_w - (x1 + e)), wy1);
+                }
+                ws[h] = w0[h] + w1[h];
+                rw[h] = refined(ws[h]);
+            }
         }
 #pragma unroll
         for (int z = 0; z < ZB; ++z)
             if (FULL || z < gn) {
-                float o[VEC];
+                f32x2 o[4];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float va = (float)Pix<uint16_t>::get(ra[z], e), vb = (float)Pix<uint16_t>::get(rb[z], e);
-                    if (FLAT) {
-                        va = div_by_refined(va, g0[e], r0[e]);
-                        vb = div_by_refined(vb, g1[e], r1[e]);
+                for (int h = 0; h < 4; ++h) {
+                    f32x2 va = {(float)(ra[z][h] & 0xFFFFu), (float)(ra[z][h] >> 16)}, vb = {0.0f, 0.0f};
+                    if constexpr (NREF == 2) vb = f32x2{(float)(rb[z][h] & 0xFFFFu), (float)(rb[z][h] >> 16)};
+                    if constexpr (FLAT != 0) {
+                        if constexpr (F32OUT) {
+                            va = va * r0[h];
+                            if constexpr (NREF == 2) vb = vb * r1[h];
+                        } else {
+                            va = div_by_refined2(va, g0[h], r0[h]);
+                            vb = div_by_refined2(vb, g1[h], r1[h]);
+                        }
                     }
-                    const float acc = __fadd_rn(__fmul_rn(w0[e], va), __fmul_rn(w1[e], vb));
-                    o[e] = div_by_refined(acc, ws[e], rw[e]);
+                    if constexpr (NREF == 2) {
+                        const f32x2 acc = w0[h] * va + w1[h] * vb;      // multiply and add separate (-ffp-contract=off), like numpy
+                        o[h] = F32OUT ? acc * rw[h] : div_by_refined2(acc, ws[h], rw[h]);
+                    } else {
+                        o[h] = va;
+                    }
                 }
                 if constexpr (F32OUT) {
                     u32x4 lo, hi;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        lo[q] = __float_as_uint(o[q]);
-                        hi[q] = __float_as_uint(o[4 + q]);
+                    for (int q = 0; q < 2; ++q) {
+                        lo[2 * q] = __float_as_uint(o[q][0]), lo[2 * q + 1] = __float_as_uint(o[q][1]);
+                        hi[2 * q] = __float_as_uint(o[2 + q][0]), hi[2 * q + 1] = __float_as_uint(o[2 + q][1]);
                     }
                     stg_nt(cplane[z] + doff + p0, lo);
                     stg_nt(cplane[z] + doff + p0 + 4, hi);
@@ -1482,7 +1548,7 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         // round half to even, negative -> 0, pack saturates to 65535
-                        const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(__builtin_rintf(o[2 * q])), cvt_u32_sat(__builtin_rintf(o[2 * q + 1])));
+                        const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(__builtin_rintf(o[q][0])), cvt_u32_sat(__builtin_rintf(o[q][1])));
                         out[q] = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
                     }
                     stg_nt(cplane[z] + doff + p0, out);
@@ -1504,24 +1570,167 @@ __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux
             p = tail_start + (l - VEC);
         }
         if (p < 0) continue;
+        if constexpr (NREF == 0) {
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) stg_s<OutT>(cplane[z] + doff + p, (OutT)0);
+            continue;
+        }
         const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
-        const float ga = FLAT ? (float)ldg_s<GM>(flat + (int64_t)y0 * P.tile_w + x0) : 1.0f, gb = FLAT ? (float)ldg_s<GM>(flat + (int64_t)y1 * P.tile_w + x1) : 1.0f;
-        const float fa = FLAT ? recip_for<1>(ga) : 1.0f, fb = FLAT ? recip_for<1>(gb) : 1.0f;
+        const float ga = FLAT ? (float)ldg_s<GM>(flat + (int64_t)y0 * P.tile_w + x0) : 1.0f;
+        const float gb = (FLAT && NREF == 2) ? (float)ldg_s<GM>(flat + (int64_t)y1 * P.tile_w + x1) : 1.0f;
+        const float fa = FLAT ? recip_for<1>(ga) : 1.0f, fb = (FLAT && NREF == 2) ? recip_for<1>(gb) : 1.0f;
         const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
         const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
         const float wsum = __fadd_rn(wa, wb), rws = recip_for<1>(wsum);
 #pragma unroll
         for (int z = 0; z < ZB; ++z)
             if (FULL || z < gn) {
-                float va = (float)ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0), vb = (float)ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
+                float va = (float)ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0), vb = 0.0f;
+                if constexpr (NREF == 2) vb = (float)ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
                 if (FLAT) {
-                    va = div_by_refined(va, ga, fa);
-                    vb = div_by_refined(vb, gb, fb);
+                    va = F32OUT ? __fmul_rn(va, fa) : div_by_refined(va, ga, fa);
+                    if constexpr (NREF == 2) vb = F32OUT ? __fmul_rn(vb, fb) : div_by_refined(vb, gb, fb);
                 }
-                const float acc = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
-                const float o = div_by_refined(acc, wsum, rws);
+                float o = va;
+                if constexpr (NREF == 2) {
+                    const float acc = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
+                    o = F32OUT ? __fmul_rn(acc, rws) : div_by_refined(acc, wsum, rws);
+                }
                 if constexpr (F32OUT) stg_s<OutT>(cplane[z] + doff + p, o);
                 else stg_s<OutT>(cplane[z] + doff + p, (OutT)min(cvt_u32_sat(__builtin_rintf(o)), 65535u));
+            }
+    }
+}
+
+// The float32 canvas in groups of FOUR voxels per thread (16 bytes out, 8 bytes of pixels in): every store instruction of a wave
+// then writes 1 KiB of a canvas row without gaps.  With eight voxels per thread a store instruction writes 16 of every 32 bytes
+// and the instruction after it the other 16: the L2 sends such half-written 64-byte pieces on as they are (WRITE_SIZE 99 GB for 85 GB
+// of canvas, profiles/r04_feather_counters.log).  Arithmetic and tolerance as in blend_item_zg's float path.  FLAT: 0 or 1.
+template <int FLAT, bool FULL, int NREF>
+__device__ __forceinline__ void blend_item_zg4(const FuseParams &P, const UnitAux &A, const int gn, const Item &it, const int tid) {
+    static_assert(FLAT == 0 || FLAT == 1, "float32 gains or none");
+    typedef uint16_t T;
+    constexpr int VEC = 4;
+    const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    float *cplane[ZB];
+    const T *t0[ZB], *t1[ZB];
+#pragma unroll
+    for (int z = 0; z < ZB; ++z) {
+        const int zz = (FULL || z < gn) ? z : 0;
+        cplane[z] = static_cast<float *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
+        t0[z] = sgpr(static_cast<const T *>(A.tile[zz]));
+        t1[z] = sgpr(static_cast<const T *>(A.ltile[zz]));
+    }
+    const float *flat = (FLAT && NREF) ? static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
+    const int ya = sgpr(A.first.b), xa = sgpr(A.first.c), yb = sgpr(A.seam.b), xb = sgpr(A.seam.c);
+    const int G = n / VEC + 1;   // upper bound of the whole groups of a row
+    auto refined2 = [](f32x2 d) {
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return pk_fma(pk_fma(-d, r, f32x2{1.0f, 1.0f}), r, r);
+    };
+    for (int idx = tid; idx < rows * G; idx += 256) {
+        const int r = idx / G, j = idx - r * G;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(float)) & (VEC - 1));
+        const int v = (mis ? 1 : 0) + j;
+        if (v >= (n + mis) / VEC) continue;
+        const int p0 = v * VEC - mis;
+        if constexpr (NREF == 0) {
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) stg_nt(cplane[z] + doff + p0, u32x4{0u, 0u, 0u, 0u});
+            continue;
+        }
+        const int y0 = ya + r, x0 = xa + p0, y1 = yb + r, x1 = xb + p0;
+        const int64_t s0 = (int64_t)y0 * P.tile_pitch + x0, s1 = (int64_t)y1 * P.tile_pitch + x1;
+        f32x2 r0[2], r1[2], w0[2], w1[2], rw[2];
+        if constexpr (FLAT != 0) {
+            const f32x4 a = ldg<F32x4U>(flat + (int64_t)y0 * P.tile_w + x0);
+            r0[0] = refined2(f32x2{a[0], a[1]}), r0[1] = refined2(f32x2{a[2], a[3]});
+            if constexpr (NREF == 2) {
+                const f32x4 b = ldg<F32x4U>(flat + (int64_t)y1 * P.tile_w + x1);
+                r1[0] = refined2(f32x2{b[0], b[1]}), r1[1] = refined2(f32x2{b[2], b[3]});
+            }
+        }
+        u32x2 ra[ZB], rb[ZB];
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                ra[z] = ldg<U32x2U>(t0[z] + s0);
+                if constexpr (NREF == 2) rb[z] = ldg<U32x2U>(t1[z] + s1);
+            }
+        if constexpr (NREF == 2) {
+            const int wy0 = min(y0 + 1, P.tile_h - y0), wy1 = min(y1 + 1, P.tile_h - y1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int e = 2 * h + c;
+                    w0[h][c] = (float)min(min(x0 + e + 1, P.tile_w - (x0 + e)), wy0);
+                    w1[h][c] = (float)min(min(x1 + e + 1, P.tile_w - (x1 + e)), wy1);
+                }
+                rw[h] = refined2(w0[h] + w1[h]);
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                u32x4 out;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 va = {(float)(ra[z][h] & 0xFFFFu), (float)(ra[z][h] >> 16)};
+                    if constexpr (FLAT != 0) va = va * r0[h];
+                    f32x2 o = va;
+                    if constexpr (NREF == 2) {
+                        f32x2 vb = {(float)(rb[z][h] & 0xFFFFu), (float)(rb[z][h] >> 16)};
+                        if constexpr (FLAT != 0) vb = vb * r1[h];
+                        o = (w0[h] * va + w1[h] * vb) * rw[h];      // multiply and add separate (-ffp-contract=off)
+                    }
+                    out[2 * h] = __float_as_uint(o[0]), out[2 * h + 1] = __float_as_uint(o[1]);
+                }
+                stg_nt(cplane[z] + doff + p0, out);
+            }
+    }
+    // the voxels before / after the 16-byte-aligned body of each row, one per thread and plane
+    for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
+        const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(float)) & (VEC - 1));
+        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int p = -1;
+        if (l < VEC) {
+            if (l < head_end) p = l;
+        } else if (tail_start + (l - VEC) < n) {
+            p = tail_start + (l - VEC);
+        }
+        if (p < 0) continue;
+        if constexpr (NREF == 0) {
+#pragma unroll
+            for (int z = 0; z < ZB; ++z)
+                if (FULL || z < gn) stg_s<float>(cplane[z] + doff + p, 0.0f);
+            continue;
+        }
+        const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
+        const float fa = FLAT ? recip_for<1>(ldg_s<float>(flat + (int64_t)y0 * P.tile_w + x0)) : 1.0f;
+        const float fb = (FLAT && NREF == 2) ? recip_for<1>(ldg_s<float>(flat + (int64_t)y1 * P.tile_w + x1)) : 1.0f;
+        const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
+        const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
+        const float rws = recip_for<1>(__fadd_rn(wa, wb));
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                float va = (float)ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0);
+                if (FLAT) va = __fmul_rn(va, fa);
+                float o = va;
+                if constexpr (NREF == 2) {
+                    float vb = (float)ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
+                    if (FLAT) vb = __fmul_rn(vb, fb);
+                    o = __fmul_rn(__fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb)), rws);
+                }
+                stg_s<float>(cplane[z] + doff + p, o);
             }
     }
 }
@@ -1564,9 +1773,30 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
         const int gn = sgpr(A.g.n);
         if (gn == 1) {
             feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
-        } else if ((F32OUT || FLAT == 2) && it.nref <= 1) {
-            // float32 canvas, or float64 gains: nothing of a one-tile (or empty) item is shared between the planes but the
-            // geometry (and gains that the grouped one-tile path does not take as doubles) -- the per-plane path, plane after plane
+        } else if (F32OUT && it.nref <= 1) {
+            // float32 canvas: one-tile and empty items through the grouped form too (gains and their reciprocals once per group,
+            // a multiply per voxel and plane -- a float canvas is held to 1e-5 relative, see blend_item_zg)
+            // (a row-wise form of this -- a wave per canvas row, scalar row bases, line-aligned slots like process_item_zg --
+            //  measured SLOWER for a float canvas: 33.3 against 29.6 ms for 20 config-3 planes, profiles/r04_exp_feather.log)
+            if constexpr (F32OUT && FLAT != 2) {
+                if (it.nref == 1) {
+                    if (gn == ZB) blend_item_zg4<FLAT, true, 1>(P, A, gn, it, threadIdx.x);
+                    else blend_item_zg4<FLAT, false, 1>(P, A, gn, it, threadIdx.x);
+                } else {
+                    if (gn == ZB) blend_item_zg4<FLAT, true, 0>(P, A, gn, it, threadIdx.x);
+                    else blend_item_zg4<FLAT, false, 0>(P, A, gn, it, threadIdx.x);
+                }
+            } else if constexpr (F32OUT) {      // float64 gains: cast once per 8-voxel group
+                if (it.nref == 1) {
+                    if (gn == ZB) blend_item_zg<FLAT, true, OutT, 1>(P, A, gn, it, threadIdx.x);
+                    else blend_item_zg<FLAT, false, OutT, 1>(P, A, gn, it, threadIdx.x);
+                } else {
+                    if (gn == ZB) blend_item_zg<FLAT, true, OutT, 0>(P, A, gn, it, threadIdx.x);
+                    else blend_item_zg<FLAT, false, OutT, 0>(P, A, gn, it, threadIdx.x);
+                }
+            }
+        } else if (FLAT == 2 && it.nref <= 1) {
+            // float64 gains: the grouped one-tile path does not take gains as doubles -- the per-plane path, plane after plane
             for (int z = 0; z < gn; ++z) feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[z]), it, wave, lane);
         } else if (it.nref <= 1) {
             Item one = it;
@@ -1584,8 +1814,13 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
                 process_item_zg<false, 1>(P, A, gn, one, wave, lane);
             }
         } else if (it.nref == 2) {
-            if (gn == ZB) blend_item_zg<FLAT, true, OutT>(P, A, gn, it, threadIdx.x);
-            else blend_item_zg<FLAT, false, OutT>(P, A, gn, it, threadIdx.x);
+            if constexpr (F32OUT && FLAT != 2) {
+                if (gn == ZB) blend_item_zg4<FLAT, true, 2>(P, A, gn, it, threadIdx.x);
+                else blend_item_zg4<FLAT, false, 2>(P, A, gn, it, threadIdx.x);
+            } else {
+                if (gn == ZB) blend_item_zg<FLAT, true, OutT>(P, A, gn, it, threadIdx.x);
+                else blend_item_zg<FLAT, false, OutT>(P, A, gn, it, threadIdx.x);
+            }
         } else {
             for (int z = 0; z < gn; ++z) blend_item<T, OutT, FLAT, true>(P, sgpr(A.g.plane[z]), it, threadIdx.x);
         }
@@ -1673,11 +1908,12 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
         if (flat_ptrs[q] == f) return;       // (flat_class_share_kernel hands the class on)
     const G lo = (G)__builtin_ldexp(1.0, FAST_MIN_EXP), hi = (G)__builtin_ldexp(1.0, FAST_END_EXP);
     const G mlo = (G)__builtin_ldexp(1.0, -MODERATE_EXP), mhi = (G)__builtin_ldexp(1.0, MODERATE_EXP);
-    bool odd = false, wide = false;
+    bool odd = false, wide = false, neg = false;
     auto look = [&](G g) {
         const G a = g < 0 ? -g : g;
         odd |= !(a >= lo && a < hi);   // NaN fails both
         wide |= !(a >= mlo && a < mhi);
+        neg |= !(g > 0);               // a gain that is not positive: weighted quotients could cancel in a blend
     };
     // 16 bytes per lane and load (the image is read at 1 TB/s with 4-byte loads from 64 workgroups: 66 us of every launch)
     constexpr int PER = 16 / sizeof(G);
@@ -1695,7 +1931,8 @@ __global__ __launch_bounds__(256) void flat_classify_kernel(const void *const *f
     }
     for (int64_t i = tid; i < head; i += nthr) look(ldg_s<G>(f + i));
     for (int64_t i = head + nvec * PER + tid; i < n; i += nthr) look(ldg_s<G>(f + i));
-    const uint32_t bits = (__builtin_amdgcn_ballot_w64(odd) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(wide) ? 2u : 0u);
+    const uint32_t bits = (__builtin_amdgcn_ballot_w64(odd) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(wide) ? 2u : 0u) |
+                          (__builtin_amdgcn_ballot_w64(neg) ? 4u : 0u);
     if (bits && (threadIdx.x & 63) == 0) atomicOr(&cls[plane], bits);
 }
 
@@ -2018,7 +2255,10 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         char *sc = static_cast<char *>(a->scratch_dev);
         uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
         PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
-        hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 3u, a->n_planes,
+        // class bits (flat_classify_kernel): 1 outside the fast divide's range, 2 not moderate, 4 not all positive.  A float32
+        // canvas takes its grouped quotients as n * (1 / g) within the north star's 1e-5 relative (blend_item_zg) -- a bound
+        // that holds for sums of same-signed terms, so planes with a non-positive gain stay with the exact per-plane blend
+        hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, f32out ? 7u : 3u, a->n_planes,
                            a->canvas_plane_stride * (int64_t)(f32out ? sizeof(float) : sizeof(uint16_t)), ZB, n_groups, groups,
                                (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
         P.groups = groups;
@@ -2028,7 +2268,7 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (P.queue) return launch_zg(fuse_feather_zg_kernel<F, true, O>, P, h.n_items, a->n_planes, stream, a->grid_blocks);    \
         return launch_zg(fuse_feather_zg_kernel<F, false, O>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                \
     } while (0)
-        if (f32out) {      // float32 canvas: the blended strips through the grouped blend, one-tile items plane after plane
+        if (f32out) {      // float32 canvas: every item through the grouped form (blend_item_zg with NREF = 2 / 1 / 0)
             if (flat == 2) SQ_FEATHER_ZG(2, float);
             if (flat == 1) SQ_FEATHER_ZG(1, float);
             SQ_FEATHER_ZG(0, float);

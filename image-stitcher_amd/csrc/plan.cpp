@@ -387,7 +387,18 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 #else
     const char *order_env = nullptr;
 #endif
-    const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : 0;
+    // Feather plans take the overwrite plans' order (2): buckets of BLOCK_ROWS TILE rows (the first reference's) dealt to the XCD
+    // lanes, so that an XCD works on a few rows of the gain image at a time -- the gains of a feather launch were fetched into
+    // the L2s 60 times over in span order (FETCH_SIZE 142 GB per 40-plane launch against 87 GB of pixels, profiles/
+    // r04_feather_counters.log).  Measured on 40 planes of config 3, uint16 canvas with gains: span order (0) 0.608, canvas
+    // raster (3: bands of 16 rows left to right, x-neighbours in one workgroup's chunk) 0.611, this 0.620 of the HBM peak
+    // (profiles/r04_exp_feather_order.log; experiment builds: SQ_FEATHER_ORDER).
+#ifdef SQ_EXPERIMENTS
+    const char *forder_env = getenv("SQ_FEATHER_ORDER");
+#else
+    const char *forder_env = nullptr;
+#endif
+    const int order_mode = mode == SQ_FUSE_OVERWRITE ? (order_env ? atoi(order_env) : 2) : (forder_env ? atoi(forder_env) : 2);
     constexpr int NX = 8;
     // order 4 ("canvas bands"): bucket = the band of BLOCK_ROWS canvas rows an item starts in, zero-fill items
     // included; spans are visited left to right so that a band's items come out in ascending x
@@ -538,6 +549,8 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         // (experiment builds, SQ_PLAN_ORDER=5: the zero-fill items dealt into the lanes by their canvas row block instead
         // of following them -- fills running beside copies instead of after them)
         if (order_mode == 5 && !it.nref) return (it.dst_y / BLOCK_ROWS) % (nblk - 1);
+        // feather items carry their row inside the SPAN (b); the tile row is the first reference's
+        if (!ow_mode) return it.nref ? std::min((refs[it.a].src_y + it.b) / BLOCK_ROWS, nblk - 2) : nblk - 1;
         return it.nref ? std::min(it.b / BLOCK_ROWS, nblk - 2) : nblk - 1;
     };
     const bool bucketed = order_mode == 1 || order_mode == 2 || order_mode == 4 || order_mode == 5;
@@ -597,8 +610,9 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
         // canvas raster order: bands of BLOCK_ROWS canvas rows, left to right; zero-fill items in place
         std::vector<size_t> idx(items.size());
         for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        const int band_rows = mode == SQ_FUSE_OVERWRITE ? BLOCK_ROWS : FEATHER_BLEND_ROWS;
         std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
-            const int ba = items[a].dst_y / BLOCK_ROWS, bb = items[b].dst_y / BLOCK_ROWS;
+            const int ba = items[a].dst_y / band_rows, bb = items[b].dst_y / band_rows;
             return ba != bb ? ba < bb : items[a].dst_x < items[b].dst_x;
         });
         for (size_t i = 0; i < idx.size(); ++i) place((int64_t)i, idx[i]);

@@ -145,6 +145,54 @@ __global__ __launch_bounds__(256) void k_regs(const Geo P) {
     }
 }
 
+// ---- A3: the shipped arithmetic, but the four waves of a workgroup on ONE row at a time (wave w the row's slot w): the workgroup
+// writes 4 KiB of one canvas row together instead of 1 KiB of four rows
+// ---- (derived from A) --------------------------------------------------------------------------------
+template <int Z, bool GAINS>
+__global__ __launch_bounds__(256) void k_regs_rowwise(const Geo P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (P.rows + 7) / 8;
+    const int tile = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int nvec = P.S / 16;
+    for (int j = 0; j < 8; ++j) {
+        const int r = blk * 8 + j;
+        if (r >= P.rows) break;
+        const RowAddr A = row_of(P, tile, r);
+        {
+            const int k = wave;
+            if (64 * k - A.shift >= nvec) continue;
+            const int i = lane + 64 * k - A.shift;
+            const bool act = i >= 0 && i < nvec;
+            const uint32_t o = (uint32_t)min(max(i, 0), nvec - 1) * 16u;
+            float g[8], rc[8];
+            if (GAINS) {
+                const f32x4 a = ((const G1 F4U *)(A.g + o * 2u))->v, b = ((const G1 F4U *)(A.g + o * 2u + 16))->v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[e] = a[e];
+                    g[4 + e] = b[e];
+                }
+            }
+            u32x4 px[Z];
+#pragma unroll
+            for (int z = 0; z < Z; ++z) px[z] = ((const G1 U4U *)(A.s + z * P.src_plane + o))->v;
+            if (GAINS) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rc[c] = __builtin_amdgcn_rcpf(g[c]);
+            }
+#pragma unroll
+            for (int z = 0; z < Z; ++z) {
+                u32x4 ov = px[z];
+                if (GAINS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ov[c] = quot_pair(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                }
+                if (act) st_nt(A.d + z * P.dst_plane + o, ov);
+            }
+        }
+    }
+}
+
 // ---- A2: the shipped structure with the quotient on the packed float32 pipe --------------------------------------------------------------------------------
 template <int Z, bool GAINS>
 __global__ __launch_bounds__(256) void k_regs_pk(const Geo P) {
@@ -1082,6 +1130,11 @@ int main(int argc, char **argv) {
         CK(hipMemset(dst, 0, Z * P.dst_plane));
         ms = time_ms([&] { hipLaunchKernelGGL((k_regs_pk<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
         report("A2 regs, quotient on the packed float32 pipe (v_pk_mul_f32 / v_pk_fma_f32)", ms, check("A2"));
+        CK(hipMemset(dst, 0, Z * P.dst_plane));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_regs_rowwise<Z, true>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("A3 regs, the 4 waves of a workgroup on ONE row at a time (wave w = slot w)", ms, check("A3"));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_regs_rowwise<Z, false>), dim3(items8), dim3(256), 0, 0, P); }, reps);
+        report("P3 plain copy in the A3 form", ms, "");
 #define RUN_B(ROWS)                                                                                                       \
     do {                                                                                                                  \
         CK(hipMemset(dst, 0, Z *P.dst_plane));                                                                            \

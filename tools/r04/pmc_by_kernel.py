@@ -17,9 +17,11 @@ def main():
     for f in files:
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                k = r['Kernel_Name'].split('(')[0]
-                if want and not any(w in k for w in want):
+                full = r['Kernel_Name']
+                if want and not any(w in full for w in want):
                     continue
+                k = full.replace('void ', '').replace('(anonymous namespace)::', '')
+                k = k.split('(')[0].strip() or full
                 c, v, disp = r['Counter_Name'], float(r['Counter_Value']), r.get('Dispatch_Id', r.get('Correlation_Id', '0'))
                 per_dispatch[(k, c, disp)] += v
                 ndisp[(k, c)].add(disp)
@@ -30,7 +32,7 @@ def main():
         agg[(k, c)].append(v)
     for (k, c) in sorted(agg):
         vals = agg[(k, c)]
-        line = f'{k:40s} {c:44s} n={len(vals):3d} mean {sum(vals) / len(vals):16.1f}  min {min(vals):16.1f}  max {max(vals):16.1f}'
+        line = f'{k:52s} {c:36s} n={len(vals):3d} mean {sum(vals) / len(vals):16.1f}  min {min(vals):16.1f}  max {max(vals):16.1f}'
         insts = [v / len(ndisp[(k, c)]) for (kk, cc, i), v in per_instance.items() if kk == k and cc == c and i]
         if len(insts) > 1:
             line += f'  | {len(insts)} instances: min {min(insts):.1f} max {max(insts):.1f}'
