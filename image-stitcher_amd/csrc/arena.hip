@@ -10,12 +10,13 @@
 // from user space, but it can be MEASURED -- two planes in one class fill at one plane's rate, two planes in different
 // classes 1.3x faster -- and HIP's virtual memory management lets the caller decide which physical memory backs which
 // virtual address.  So:
-//   1. take the memory in SLICES (hipMemCreate; 64 MiB each by default), map them in creation order into one reserved
-//      virtual range (hipMemAddressReserve / hipMemMap);
-//   2. classify UNITS (512 MiB of consecutively created slices: physical memory is handed out in long runs) by the pair
-//      fill against reference units: class 0 = whatever collides with unit 0, class 1 = whatever collides with the first unit
-//      outside class 0, ...;
-//   3. unmap, and map the slices again ROUND-ROBIN over the classes.
+//   1. take candidate memory in SLICES (hipMemCreate; 64 MiB each by default), chunk by chunk, mapped in creation order into
+//      one reserved virtual range (hipMemAddressReserve / hipMemMap);
+//   2. classify UNITS (512 MiB of consecutively created slices: physical memory is handed out in long runs) as they come: a
+//      unit joins the first class whose reference unit it collides with -- the pair fills less than 1.17 times faster than the
+//      reference alone -- or becomes the reference of a new class; stop taking memory once the three largest classes each
+//      hold a third of the arena (or the caller's cap is reached, or the card is full);
+//   3. choose the arena's slices round-robin over the classes, give the others back, and map the chosen ones in that order.
 // Every 200 MB of such an arena then holds all classes, wherever a plane starts and however many planes a launch writes:
 // one plane alone fills at 0.72-0.75, five consecutive planes at 0.75-0.76, the fusion kernel's structure goes from
 // 0.61-0.62 to 0.71 (tools/membw_gains 700, profiles/r04_exp_mixed_arena.log).  Reads do not care (tiles may live anywhere).
@@ -29,6 +30,8 @@
 #include <algorithm>
 #include <cstring>
 #include <ctime>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -40,7 +43,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // The probe's write pattern: a G x G grid of tiles, every tile `rows` row segments of SEG bytes at `pitch`, one workgroup per
 // (tile, block of 8 rows), wave w the rows w and w + 4, 16 bytes per lane -- the fusion kernel's access pattern without its
-// reads -- into TWO planes at once (the same offsets in both).
+// reads -- into TWO planes at once (the same offsets in both), or into one (d1 == NULL).
 constexpr int PROBE_SEG = 3600, PROBE_ROWS = 1800;
 
 __global__ __launch_bounds__(256) void arena_pair_fill_kernel(char *d0, char *d1, int G, size_t pitch) {
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void arena_pair_fill_kernel(char *d0, char *d1
             const int i = lane + 64 * k;
             if (i < nvec) {
                 __builtin_nontemporal_store(v, (SQ_G1 u32x4 *)(d0 + off + (size_t)i * 16));
-                __builtin_nontemporal_store(v, (SQ_G1 u32x4 *)(d1 + off + (size_t)i * 16));
+                if (d1) __builtin_nontemporal_store(v, (SQ_G1 u32x4 *)(d1 + off + (size_t)i * 16));
             }
         }
     }
@@ -120,9 +123,18 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         return nullptr;
     }
     const size_t slice = slice_bytes > 0 ? (size_t)slice_bytes : ((size_t)64 << 20);
-    size_t unit = unit_bytes > 0 ? (size_t)unit_bytes : ((size_t)512 << 20);
+    const size_t unit = unit_bytes > 0 ? (size_t)unit_bytes : ((size_t)512 << 20);
     if (slice % ((size_t)2 << 20) || unit % slice) {
         sq::fail(SQ_ERR_INVALID, "sq_arena_create: the slice must be a multiple of 2 MiB and the unit a multiple of the slice");
+        return nullptr;
+    }
+    // the probe's geometry: the largest G x G grid of row segments that fits a unit
+    int G = 16;
+    for (; G > 1; --G)
+        if ((size_t)G * PROBE_ROWS * ((size_t)G * PROBE_SEG + 560) <= unit) break;
+    const size_t pitch = (size_t)G * PROBE_SEG + 560;
+    if ((size_t)G * PROBE_ROWS * pitch > unit) {
+        sq::fail(SQ_ERR_INVALID, "sq_arena_create: a unit of %zu bytes is too small for the probe (>= 16 MiB)", unit);
         return nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -132,42 +144,25 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         delete a;
         return nullptr;
     }
-    // n slices make the arena; up to ncand are taken and classified so that the arena can be BALANCED over the classes (a third
-    // each): what hipMalloc-order memory offers is runs of tens of GiB of one class, and an arena of 50 GiB taken as it comes
-    // was 65 % one class.  The slices not chosen go back to the driver before the call returns.
+    // n slices make the arena.  Memory comes in runs of tens of GiB of one class, so candidates are taken chunk by chunk and
+    // classified as they come, until the three largest classes each hold a third of the arena (or `cap` slices are taken, or
+    // the card is full); the slices not chosen go back to the driver before the call returns.
+    const bool natural = (flags & SQ_ARENA_NATURAL_ORDER) != 0;
     const size_t n = ((size_t)bytes + slice - 1) / slice;
-    size_t ncand = std::max(n, candidate_bytes > 0 ? (size_t)candidate_bytes / slice : n);
-    if (flags & SQ_ARENA_NATURAL_ORDER) ncand = n;
+    const size_t spu = unit / slice;
+    const size_t cap = natural ? n : std::max(n, candidate_bytes > 0 ? (size_t)candidate_bytes / slice : n);
+    const size_t chunk = std::max<size_t>(8 * spu, (n / 2 + spu - 1) / spu * spu);      // >= 4 GiB at the default sizes
     a->slice = slice;
-    a->bytes = n * slice;
     const double t0 = now_s();
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = a->device;
-    a->handles.reserve(ncand);
-    for (size_t i = 0; i < ncand; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        hipError_t e = hipMemCreate(&h, slice, &prop, 0);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (i >= n && e == hipErrorOutOfMemory) {      // fewer candidates than asked for: the card is full, go on with these
-                ncand = i;
-                break;
-            }
-            sq::fail(e == hipErrorNotSupported ? SQ_ERR_UNSUPPORTED : SQ_ERR_HIP,
-                     "sq_arena_create: %shipMemCreate of slice %zu of %zu (%zu MiB each) failed: %s",
-                     e == hipErrorNotSupported ? "virtual memory management unsupported: " : "", i, n, slice >> 20, hipGetErrorString(e));
-            release(a);
-            return nullptr;
-        }
-        a->handles.push_back(h);
-    }
-    if (trace_on()) fprintf(stderr, "[sq_arena] hipMemCreate x %zu (%zu MiB each): %.1f ms\n", ncand, slice >> 20, (now_s() - t0) * 1e3);
-    double tp = now_s();
-    // the candidates, in creation order, in a virtual range of their own for the probe
-    const size_t cand_bytes = ncand * slice;
-    a->bytes = cand_bytes;      // (release() unmaps / frees what `bytes` says while the candidates are mapped)
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t cand_bytes = cap * slice;
+    a->bytes = cand_bytes;      // (release() unmaps / frees what `bytes` says while the candidates' range exists)
     hipError_t e = hipMemAddressReserve((void **)&a->base, cand_bytes, (size_t)1 << 30, nullptr, 0);
     if (e != hipSuccess) {
         a->base = nullptr;
@@ -176,134 +171,175 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         release(a);
         return nullptr;
     }
-    std::vector<int> order(ncand);
-    for (size_t i = 0; i < ncand; ++i) order[i] = (int)i;
-    if (map_in_order(a, order) != SQ_OK) {
+    a->handles.reserve(cap);
+    sq_arena_info &I = a->info;
+    std::vector<int> cls;                 // class of every whole unit taken so far
+    std::vector<int> ref_unit;            // per class: its reference unit ...
+    std::vector<size_t> class_slices_taken;
+    float probe_ms = 0;
+    double glo = 1e30, ghi = 0, t_create = 0, t_map = 0;
+    const unsigned grid = (unsigned)(G * G * ((PROBE_ROWS + 7) / 8));
+    const double plane_bytes = (double)G * G * PROBE_ROWS * PROBE_SEG;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    bool bad = false;
+    // GB/s written by the fill of unit u alone (v < 0) or of the pair (u, v): the first launch warms up, best of the other two
+    auto fill_rate = [&](int u, int v) {
+        char *d0 = a->base + (size_t)u * unit, *d1 = v >= 0 ? a->base + (size_t)v * unit : nullptr;
+        double best = 1e30;
+        for (int rep = 0; rep < 3 && !bad; ++rep) {
+            (void)hipEventRecord(e0, st);
+            hipLaunchKernelGGL(arena_pair_fill_kernel, dim3(grid), dim3(256), 0, st, d0, d1, G, pitch);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { bad = true; break; }
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            probe_ms += ms;
+            if (rep && ms < best) best = ms;
+        }
+        return (v >= 0 ? 2.0 : 1.0) * plane_bytes / best / 1e6;
+    };
+    // Two planes in ONE class fill at about the rate of one plane alone, two planes in different classes 1.2-1.3 times faster
+    // (profiles/r04_exp_placement_counters.log; with this probe's small geometry: alone 4.2, same class 4.3-4.7, different
+    // classes 5.1-5.35 TB/s).  A unit COLLIDES with a class when its pair with the class' reference unit is on the slow side of
+    // what that reference has been seen to do -- below the midpoint of its slowest and fastest pair once those are 12 % apart;
+    // before a reference has shown both behaviours the rate of the reference alone decides (a pair less than 1.17 times
+    // faster collides).  Every measured pair is kept, and the whole assignment is re-derived from the kept rates after every
+    // chunk of candidates, so a decision taken before a reference's two populations were known does not stick.
+    std::map<std::pair<int, int>, double> pair_rate;
+    std::map<int, double> alone_rate;
+    auto pair_of = [&](int r, int u) {
+        auto it = pair_rate.find({r, u});
+        if (it != pair_rate.end()) return it->second;
+        const double v = fill_rate(r, u);
+        glo = std::min(glo, v);
+        ghi = std::max(ghi, v);
+        pair_rate[{r, u}] = v;
+        return v;
+    };
+    auto alone_of = [&](int r) {
+        auto it = alone_rate.find(r);
+        if (it != alone_rate.end()) return it->second;
+        return alone_rate[r] = fill_rate(r, -1);
+    };
+    auto collides = [&](int r, double v) {
+        double lo = 1e30, hi = 0;
+        for (auto it = pair_rate.lower_bound({r, -1}); it != pair_rate.end() && it->first.first == r; ++it) {
+            lo = std::min(lo, it->second);
+            hi = std::max(hi, it->second);
+        }
+        if (hi > 1.12 * lo) return v < 0.5 * (lo + hi);
+        return v < 1.17 * alone_of(r);
+    };
+    // classes of the units taken so far, from scratch: a unit joins the first class (in order of creation) it collides with,
+    // else it founds one; twice, so that the second round decides with every rate of the first on the table
+    auto classify_all = [&](size_t nunits) {
+        for (int round = 0; round < 2 && !bad; ++round) {
+            ref_unit.clear();
+            cls.assign(nunits, -1);
+            for (size_t u = 0; u < nunits && !bad; ++u) {
+                int got = -1;
+                for (size_t c = 0; c < ref_unit.size() && got < 0; ++c)
+                    if (collides(ref_unit[c], pair_of(ref_unit[c], (int)u))) got = (int)c;
+                if (got < 0) {
+                    if ((int)ref_unit.size() < SQ_ARENA_MAX_CLASSES) {
+                        ref_unit.push_back((int)u);
+                        got = (int)ref_unit.size() - 1;
+                    } else {
+                        got = SQ_ARENA_MAX_CLASSES - 1;      // more populations than slots: the last takes the rest
+                    }
+                }
+                cls[u] = got;
+            }
+        }
+        class_slices_taken.assign(ref_unit.size(), 0);
+        for (size_t u = 0; u < nunits; ++u) class_slices_taken[cls[u]] += spu;
+    };
+    auto balanced = [&]() {
+        std::vector<size_t> c(class_slices_taken);
+        std::sort(c.rbegin(), c.rend());
+        return c.size() >= 3 && c[2] >= (n + 2) / 3;
+    };
+    size_t have = 0;
+    bool full = false;
+    while (have < cap && !full && !bad) {
+        const size_t want = std::min(have == 0 ? std::max(n, chunk) : chunk, cap - have);
+        double tc = now_s();
+        size_t got = 0;
+        for (; got < want; ++got) {
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, slice, &prop, 0);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (have + got >= n && e == hipErrorOutOfMemory) {      // the card is full: go on with what there is
+                    full = true;
+                    break;
+                }
+                sq::fail(e == hipErrorNotSupported ? SQ_ERR_UNSUPPORTED : SQ_ERR_HIP,
+                         "sq_arena_create: %shipMemCreate of slice %zu of %zu (%zu MiB each) failed: %s",
+                         e == hipErrorNotSupported ? "virtual memory management unsupported: " : "", have + got, n, slice >> 20, hipGetErrorString(e));
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                a->mapped = have > 0;
+                a->bytes = have * slice;
+                if (a->mapped) (void)hipMemUnmap(a->base, a->bytes);
+                a->mapped = false;
+                a->bytes = cand_bytes;
+                release(a);
+                return nullptr;
+            }
+            a->handles.push_back(h);
+        }
+        t_create += now_s() - tc;
+        tc = now_s();
+        for (size_t i = have; i < have + got && !bad; ++i)
+            if (hipMemMap(a->base + i * slice, slice, 0, a->handles[i], 0) != hipSuccess) bad = true;
+        if (!bad && got && hipMemSetAccess(a->base + have * slice, got * slice, &acc, 1) != hipSuccess) bad = true;
+        t_map += now_s() - tc;
+        have += got;
+        if (natural || bad) break;
+        classify_all(have / spu);
+        if (balanced()) break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const size_t ncand = have;
+    auto unmap_candidates = [&]() {
+        (void)hipStreamSynchronize(st);
+        if (ncand) (void)hipMemUnmap(a->base, ncand * slice);
+        (void)hipMemAddressFree(a->base, cand_bytes);
+        a->base = nullptr;
+        a->mapped = false;
+    };
+    if (bad || hipGetLastError() != hipSuccess || ncand < n) {
+        sq::fail(SQ_ERR_HIP, "sq_arena_create: mapping or probing the candidate slices failed");
+        unmap_candidates();
         release(a);
         return nullptr;
     }
-    if (trace_on()) fprintf(stderr, "[sq_arena] reserve + map + set access of the candidates: %.1f ms\n", (now_s() - tp) * 1e3);
-    tp = now_s();
-    sq_arena_info &I = a->info;
-    I.slice_bytes = (int64_t)slice;
-    I.n_slices = (int32_t)n;
-    I.n_candidates = (int32_t)ncand;
-    I.n_classes = 1;
-    I.interleaved = 0;
-
-    // ---- classify the units ------------------------------------------------------------------------------------------
-    const size_t spu = unit / slice;
-    const int nu = (int)(ncand / spu);      // whole units; a tail shorter than a unit takes the class of the unit before it
-    std::vector<int> cls(std::max(nu, 1), -1);
-    int ncls = 1;
-    float probe_ms = 0;
-    double glo = 1e30, ghi = 0;
-    if (!(flags & SQ_ARENA_NATURAL_ORDER) && nu >= 2) {
-        int G = 16;
-        size_t pitch = 0;
-        for (; G > 1; --G) {
-            pitch = (size_t)G * PROBE_SEG + 560;
-            if ((size_t)G * PROBE_ROWS * pitch <= unit) break;
-        }
-        pitch = (size_t)G * PROBE_SEG + 560;
-        if ((size_t)G * PROBE_ROWS * pitch > unit) {
-            sq::fail(SQ_ERR_INVALID, "sq_arena_create: a unit of %zu bytes is too small for the probe (>= 16 MiB)", unit);
-            release(a);
-            return nullptr;
-        }
-        const unsigned grid = (unsigned)(G * G * ((PROBE_ROWS + 7) / 8));
-        const double moved = 2.0 * G * G * (double)PROBE_ROWS * PROBE_SEG;      // bytes one pair fill writes
-        hipEvent_t e0, e1, p0, p1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipEventCreate(&p0);
-        (void)hipEventCreate(&p1);
-        (void)hipEventRecord(p0, st);
-        std::vector<double> rate(nu);
-        ncls = 0;
-        bool bad = false;
-        for (; ncls < SQ_ARENA_MAX_CLASSES && !bad; ++ncls) {
-            int ref = -1;
-            for (int k = 0; k < nu; ++k)
-                if (cls[k] < 0) { ref = k; break; }
-            if (ref < 0) break;
-            cls[ref] = ncls;
-            double lo = 1e30, hi = 0;
-            for (int k = 0; k < nu; ++k) {
-                if (cls[k] >= 0) continue;
-                char *d0 = a->base + (size_t)ref * unit, *d1 = a->base + (size_t)k * unit;
-                double best = 1e30;
-                for (int rep = 0; rep < 3; ++rep) {      // the first launch warms up (page tables, clocks); best of the other two
-                    (void)hipEventRecord(e0, st);
-                    hipLaunchKernelGGL(arena_pair_fill_kernel, dim3(grid), dim3(256), 0, st, d0, d1, G, pitch);
-                    (void)hipEventRecord(e1, st);
-                    if (hipEventSynchronize(e1) != hipSuccess) { bad = true; break; }
-                    float ms = 0;
-                    (void)hipEventElapsedTime(&ms, e0, e1);
-                    if (rep && ms < best) best = ms;
-                }
-                if (bad) break;
-                rate[k] = moved / best / 1e6;      // GB/s
-                lo = std::min(lo, rate[k]);
-                hi = std::max(hi, rate[k]);
-            }
-            if (bad) break;
-            if (hi == 0) {      // nothing left to compare with: the reference is the last class, alone in it
-                ++ncls;
-                break;
-            }
-            glo = std::min(glo, lo);
-            ghi = std::max(ghi, hi);
-            // two populations (collides with the reference / does not) are ~25 % apart; inside one the spread is ~3 %
-            double cut;
-            if (hi - lo > 0.10 * hi) cut = 0.5 * (lo + hi);
-            else if (ncls == 0) cut = 1e30;                              // nothing stands out: one class
-            else cut = lo < 0.5 * (glo + ghi) ? 1e30 : -1;               // all collide with this reference / none does
-            for (int k = 0; k < nu; ++k)
-                if (cls[k] < 0 && rate[k] < cut) cls[k] = ncls;
-        }
-        (void)hipEventRecord(p1, st);
-        (void)hipEventSynchronize(p1);
-        (void)hipEventElapsedTime(&probe_ms, p0, p1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        (void)hipEventDestroy(p0);
-        (void)hipEventDestroy(p1);
-        if (bad || hipGetLastError() != hipSuccess) {
-            sq::fail(SQ_ERR_HIP, "sq_arena_create: the classification probe failed");
-            release(a);
-            return nullptr;
-        }
-        for (int k = 0; k < nu; ++k)
-            if (cls[k] < 0) cls[k] = ncls - 1;      // more populations than SQ_ARENA_MAX_CLASSES: the rest joins the last one
-        ncls = std::max(ncls, 1);
-    } else {
-        std::fill(cls.begin(), cls.end(), 0);
-    }
-
+    const int nu = (int)cls.size();
+    const int ncls = std::max<int>(1, (int)ref_unit.size());
     if (trace_on()) {
-        fprintf(stderr, "[sq_arena] probe: %.1f ms host, %.1f ms device, %d classes; units in creation order: ", (now_s() - tp) * 1e3, probe_ms, ncls);
+        fprintf(stderr, "[sq_arena] %zu candidate slices of %zu MiB for an arena of %zu: hipMemCreate %.1f ms, map %.1f ms, probe %.1f ms on the device, %d classes\n"
+                        "[sq_arena] units in creation order: ", ncand, slice >> 20, n, t_create * 1e3, t_map * 1e3, probe_ms, ncls);
         for (int k = 0; k < nu; ++k) fputc('A' + cls[k], stderr);
         fputc('\n', stderr);
     }
-    tp = now_s();
+    double tp = now_s();
+
     // ---- choose n slices round-robin over the classes, give the rest back, map the chosen ones -------------------------------
-    auto class_of_slice = [&](size_t s) { return cls[std::min((size_t)std::max(nu, 1) - 1, s / spu)]; };
+    auto class_of_slice = [&](size_t s) { return nu ? cls[std::min((size_t)nu - 1, s / spu)] : 0; };
+    I.slice_bytes = (int64_t)slice;
+    I.n_slices = (int32_t)n;
+    I.n_candidates = (int32_t)ncand;
     I.n_classes = ncls;
     I.probe_ms = probe_ms;
     I.min_pair_gbs = ghi > 0 ? (float)glo : 0.f;
     I.max_pair_gbs = (float)ghi;
     for (int c = 0; c < SQ_ARENA_MAX_CLASSES; ++c) I.class_slices[c] = I.class_candidates[c] = 0;
     for (size_t s = 0; s < ncand; ++s) I.class_candidates[class_of_slice(s)]++;
-    if (hipStreamSynchronize(st) != hipSuccess || hipMemUnmap(a->base, cand_bytes) != hipSuccess) {
-        sq::fail(SQ_ERR_HIP, "sq_arena_create: hipMemUnmap failed");
-        a->mapped = false;
-        release(a);
-        return nullptr;
-    }
-    a->mapped = false;
-    (void)hipMemAddressFree(a->base, cand_bytes);
-    a->base = nullptr;
+    unmap_candidates();
     if (trace_on()) fprintf(stderr, "[sq_arena] unmap + free of the candidates' range: %.1f ms\n", (now_s() - tp) * 1e3);
     tp = now_s();
     std::vector<int> chosen;

@@ -629,7 +629,14 @@ __device__ __forceinline__ void for_each_queued_item(const FuseParams &P, const 
     // (harmless) and skipped their share of the new one.  Found in round 3 as 28 ... 508 unwritten voxels in 1-2 % of the
     // launches of the per-plane feather kernel on a small plan (tools/queue_stress.py; the plane-group kernels never
     // showed it in thousands of launches, but their code had the same gap).
-    auto lds_written = [] { __builtin_amdgcn_s_waitcnt(0xc07f); };      // gfx9 encoding: lgkmcnt(0), vmcnt / expcnt untouched
+    // 0xc07f is the s_waitcnt immediate of the gfx9 family (vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]): lgkmcnt(0) with
+    // vmcnt / expcnt at their maxima.  gfx10+ lay the fields out differently -- there the same bits would wait on something else
+    // and the race would be back, silently -- so a device pass for anything but gfx9 stops here (tools/barrier_scan.py,
+    // run by tests/test_isa_cpu.py, checks the listing of the build that ships).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "lds_written(): the s_waitcnt immediate below is the gfx9 encoding; re-derive it for this target"
+#endif
+    auto lds_written = [] { __builtin_amdgcn_s_waitcnt(0xc07f); };
     if (threadIdx.x == 0) {
         const Chunk first = settle(atomicAdd(&P.queue[queue_of(0) * QUEUE_STRIDE], 1u));
         s_q[0] = first.q;

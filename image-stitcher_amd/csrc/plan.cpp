@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -36,12 +37,47 @@ void parallel_ranges(int nthreads, size_t n, F fn) {
         fn(0, (size_t)0, n);
         return;
     }
+    // An exception in a worker (std::bad_alloc from a reserve, say) must not reach the top of its thread -- that is
+    // std::terminate for the whole process: the first one is kept and re-thrown on the calling thread after the join, where
+    // the entry points turn it into a status (guarded(), below).
     std::vector<std::thread> pool;
     pool.reserve(nthreads - 1);
+    std::exception_ptr failed;
+    std::mutex failed_mutex;
     auto bound = [&](int t) { return n * (size_t)t / (size_t)nthreads; };
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back([&, t] { fn(t, bound(t), bound(t + 1)); });
-    fn(0, bound(0), bound(1));
+    auto run = [&](int t) {
+        try {
+            fn(t, bound(t), bound(t + 1));
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(failed_mutex);
+            if (!failed) failed = std::current_exception();
+        }
+    };
+    size_t started = 0;
+    try {
+        for (int t = 1; t < nthreads; ++t, ++started) pool.emplace_back(run, t);
+    } catch (...) {      // no more threads to be had: the ranges not started run here, below
+        std::lock_guard<std::mutex> lock(failed_mutex);
+        if (!failed) failed = std::current_exception();
+    }
+    run(0);
     for (auto &th : pool) th.join();
+    if (failed) std::rethrow_exception(failed);
+}
+
+// the planner's entry points are extern "C": nothing may propagate out of them
+template <typename F>
+sq_fuse_plan *guarded(const char *what, F make) {
+    try {
+        return make();
+    } catch (const std::bad_alloc &) {
+        sq::fail(SQ_ERR_INVALID, "%s: out of host memory while planning", what);
+    } catch (const std::exception &e) {
+        sq::fail(SQ_ERR_INVALID, "%s: %s", what, e.what());
+    } catch (...) {
+        sq::fail(SQ_ERR_INVALID, "%s: unknown failure while planning", what);
+    }
+    return nullptr;
 }
 
 struct Clipped {
@@ -359,8 +395,8 @@ bool make_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t t
 
 extern "C" {
 
-sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
-                                  int32_t canvas_h, int32_t canvas_w, int32_t mode) {
+static sq_fuse_plan *plan_create_impl(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+                                      int32_t canvas_h, int32_t canvas_w, int32_t mode) {
     SpanStage S;
     if (!make_spans(rects, n_rects, tile_h, tile_w, canvas_h, canvas_w, mode, "sq_fuse_plan_create", S)) return nullptr;
     std::vector<Span> &spans = S.spans;
@@ -667,13 +703,22 @@ sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t
 #else
     (void)t_begin; (void)t_sweep; (void)t_items; (void)t_order; (void)n_spans_dbg; (void)t_gen; (void)t_band; (void)t_sort;
 #endif
+    // The per-thread work lists keep their capacity for the next plan of this thread (a 32 x 32 grid's ~30 MB are cheaper to keep
+    // than to fault in again), but not without bound: past SCRATCH_KEEP_BYTES they go back, so a thread that once planned a
+    // 100 x 100 grid does not hold a third of a GB for the rest of its life.
+    constexpr size_t SCRATCH_KEEP_BYTES = (size_t)64 << 20;
+    if (items.capacity() * sizeof(Item) + seams.capacity() * sizeof(Seam) + by_band.capacity() * sizeof(int32_t) > SCRATCH_KEEP_BYTES) {
+        std::vector<Item>().swap(items);
+        std::vector<Seam>().swap(seams);
+        std::vector<int32_t>().swap(by_band);
+    }
     return plan;
 }
 
 // The plan up to its spans; items, seam owners and their order follow on the device (sq_fuse_plan_expand).  The table
 // layout is the complete plan's: header | spans | refs | items | seams -- the host copy ends after the refs (plus the
 // spans' first item numbers, which the expansion kernels read from their scratch).
-sq_fuse_plan *sq_fuse_plan_create_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
+static sq_fuse_plan *plan_create_spans_impl(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w,
                                         int32_t canvas_h, int32_t canvas_w, int32_t mode) {
     if (mode != SQ_FUSE_OVERWRITE) {
         fail(SQ_ERR_UNSUPPORTED, "sq_fuse_plan_create_spans: overwrite plans only (mode %d)", mode);
@@ -735,6 +780,18 @@ sq_fuse_plan *sq_fuse_plan_create_spans(const sq_rect *rects, int32_t n_rects, i
     if (!S.refs.empty()) std::memcpy(p + hd.off_refs, S.refs.data(), S.refs.size() * sizeof(Ref));
     std::memcpy(p + plan->off_span_first, span_first.data(), (ns + 1) * 8);
     return plan;
+}
+
+
+sq_fuse_plan *sq_fuse_plan_create(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w, int32_t canvas_h,
+                                  int32_t canvas_w, int32_t mode) {
+    return guarded("sq_fuse_plan_create", [&] { return plan_create_impl(rects, n_rects, tile_h, tile_w, canvas_h, canvas_w, mode); });
+}
+
+sq_fuse_plan *sq_fuse_plan_create_spans(const sq_rect *rects, int32_t n_rects, int32_t tile_h, int32_t tile_w, int32_t canvas_h,
+                                        int32_t canvas_w, int32_t mode) {
+    return guarded("sq_fuse_plan_create_spans",
+                   [&] { return plan_create_spans_impl(rects, n_rects, tile_h, tile_w, canvas_h, canvas_w, mode); });
 }
 
 void sq_fuse_plan_destroy(sq_fuse_plan *plan) { delete plan; }

@@ -201,7 +201,9 @@ class FusePlan:
     ``expand_on_device=True`` (overwrite plans): the host stops after the sweep into spans and ``device_table`` has the
     work list -- items, seam owners, their order -- produced by kernels in device memory (sq_fuse_plan_create_spans /
     sq_fuse_plan_expand; the table is the host planner's byte for byte, tests/test_plan_gpu.py): what a job pays between
-    registration and its first fusion launch drops from ~5.5 ms + a 14.7 MB upload to ~1.5 ms for a 32 x 32 grid."""
+    registration and its first fusion launch drops from ~5.5 ms + a 14.7 MB upload to ~1.5 ms for a 32 x 32 grid.
+    ``device_table`` is serialised per plan (the expansion writes the plan's host header), and a table whose expansion or
+    upload failed is not kept: the next call starts over."""
 
     def __init__(self, rects, tile_h: int, tile_w: int, canvas_h: int, canvas_w: int, mode: int = SQ_FUSE_OVERWRITE,
                  expand_on_device: bool = False):
@@ -223,6 +225,8 @@ class FusePlan:
         _check(L.sq_fuse_plan_stats(self._h, C.byref(ns), C.byref(ni), C.byref(cv), C.byref(mr)), 'sq_fuse_plan_stats')
         self.n_spans, self.n_items, self.covered_voxels, self.max_refs = ns.value, ni.value, cv.value, mr.value
         self._dev = {}
+        import threading
+        self._lock = threading.Lock()
 
     @property
     def handle(self) -> int:
@@ -246,6 +250,11 @@ class FusePlan:
         storage; sq_fuse_plan_upload waits for it, so the plan can be dropped at any time)."""
         import torch
         key = str(device)
+        with self._lock:      # sq_fuse_plan_expand writes the plan's host header: one expansion (or upload) at a time per plan
+            return self._device_table_locked(key, device)
+
+    def _device_table_locked(self, key, device):
+        import torch
         if key not in self._dev:
             # on the read-back / upload stream, not the caller's: the copy must not queue behind a fusion
             # launch that is still running there (the entry point waits for the copy, so the table is
@@ -436,11 +445,11 @@ class DeviceArena:
         info = _ArenaInfo()
         with torch.cuda.device(self.device):
             if candidate_bytes is None:
-                # memory comes in runs of tens of GiB of one class: take up to three times what is needed -- or what is free
-                # but for a reserve -- classify it, keep a third per class and give the rest back (create the arena FIRST,
-                # while the card is empty)
+                # memory comes in runs of tens of GiB of one class: the call may take what is free (but for a reserve), chunk by
+                # chunk, until every class holds a third of the arena, and gives the rest back (create the arena FIRST, while
+                # the card is empty: it then takes 1.5-2.5 times its size for ~25 ms per GiB)
                 free = torch.cuda.mem_get_info(self.device)[0]
-                candidate_bytes = max(int(nbytes), min(3 * int(nbytes), free - (6 << 30)))
+                candidate_bytes = max(int(nbytes), min(8 * int(nbytes), free - (6 << 30)))
             self._h = L.sq_arena_create(int(nbytes), int(candidate_bytes), int(slice_bytes), int(unit_bytes),
                                         SQ_ARENA_NATURAL_ORDER if natural_order else 0, _stream_ptr(stream), C.byref(info))
         if not self._h:

@@ -166,9 +166,10 @@ int sq_fuse_planes(const sq_fuse_args *args, void *stream);
  * stride and however the planes are grouped.  The caller sub-allocates (the arena is a flat range; canvases want their
  * planes on 128-byte lines, see sq_fuse_args) and destroys it when no kernel uses it any more.  Synchronises `stream`.
  * Tiles, gains and plans may live anywhere: reads do not depend on the class.
- *   candidate_bytes: memory taken and classified before `bytes` of it are chosen, a third per class, and the rest given
- *       back (0 = bytes: whatever comes).  Memory comes in runs of tens of GiB of one class, so an arena is only balanced
- *       when it can choose: 3 x bytes -- or what is free -- while the card is still empty, i.e. create the arena FIRST.
+ *   candidate_bytes: the most memory the call may take while it looks for a balanced arena (0 = bytes: whatever comes).  Memory
+ *       comes in runs of tens of GiB of one class, so candidates are taken chunk by chunk and classified until the three largest
+ *       classes each hold a third of `bytes`; the rest is given back before the call returns.  Pass what is free (less a
+ *       reserve) and create the arena FIRST, while the card is still empty: typically 1.5-2.5 x bytes are taken, ~25 ms / GiB.
  *   slice_bytes: 0 = 64 MiB (a multiple of 2 MiB);  unit_bytes: 0 = 512 MiB (a multiple of the slice, >= 16 MiB)
  *   flags: SQ_ARENA_NATURAL_ORDER = skip the probe and keep the slices in creation order (the control of A/B runs)
  * Returns NULL on failure (sq_last_error; SQ_ERR_UNSUPPORTED in the message when the platform lacks virtual memory

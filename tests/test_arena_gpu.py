@@ -23,12 +23,13 @@ def _torch():
 def test_arena_is_classified_balanced_and_aliases_like_plain_memory():
     torch = _torch()
     dev = torch.device('cuda:0')
-    # 256 MiB chosen from 768 MiB of candidates: 8 MiB slices, 32 MiB probe units (the production sizes are 64 / 512 MiB)
+    # 256 MiB chosen from up to 768 MiB of candidates: 8 MiB slices, 32 MiB probe units (the production sizes are 64 / 512 MiB)
     arena = native.DeviceArena(256 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=768 * MiB)
     info = arena.info
-    assert info['bytes'] == 256 * MiB == arena.nbytes and info['n_slices'] == 32 and info['n_candidates'] == 96
+    # candidates are taken chunk by chunk until the three largest classes each hold a third of the arena, 768 MiB at most
+    assert info['bytes'] == 256 * MiB == arena.nbytes and info['n_slices'] == 32 and 32 <= info['n_candidates'] <= 96
     assert 1 <= info['n_classes'] <= native.SQ_ARENA_MAX_CLASSES
-    assert sum(info['class_slices']) == 32 and sum(info['class_candidates']) == 96
+    assert sum(info['class_slices']) == 32 and sum(info['class_candidates']) == info['n_candidates']
     assert info['interleaved'] == (info['n_classes'] > 1) and info['probe_ms'] > 0 and info['max_pair_gbs'] >= info['min_pair_gbs'] > 0
     if info['n_classes'] > 1:      # round-robin: no class gives more than its share + 1 while another still has candidates
         fair = -(-32 // info['n_classes'])
