@@ -432,7 +432,10 @@ class PlaneStreamWriter:
                     frames[:total].copy_(enc.out[:total], non_blocking=True)
             done.record()
         done.synchronize()
-        jobs = []
+        # one native call per pyramid level (native.write_files: open / write / close on native threads, straight from the
+        # page-locked frame buffer): the paths and the directories are worked out here, a few hundred directories per batch
+        from . import native
+        written = 0
         for lv, (enc, (frames, offsets, _)) in enumerate(zip(self._enc[slot], self._host[slot])):
             n_planes_geo, h, w, _, cy, cx = enc.geometry
             ncy, ncx = -(-h // cy), -(-w // cx)
@@ -441,24 +444,31 @@ class PlaneStreamWriter:
             if y_off % cyf:
                 raise ValueError(f"row band at level-0 row {self.row_offset} does not start on a chunk row of level {lv}")
             off = offsets.numpy()
-            buf = frames.numpy()
-            for i, (t, c, z) in enumerate(coords):
-                base = i * ncy * ncx
-                for iy in range(ncy):
-                    for ix in range(ncx):
-                        a, b = int(off[base + iy * ncx + ix]), int(off[base + iy * ncx + ix + 1])
-                        if b > a:
-                            jobs.append((lv, t, c, z, y_off // cyf + iy, ix, buf[a:b]))
-
-        def put(job):
-            lv, t, c, z, iy, ix, data = job
-            cdir = os.path.join(self.path, str(lv), str(t), str(c), str(z), str(iy))
-            os.makedirs(cdir, exist_ok=True)
-            with open(os.path.join(cdir, str(ix)), 'wb') as fh:
-                fh.write(memoryview(data))
-            return len(data)
-
-        return sum(self._pool.map(put, jobs))
+            per_plane = ncy * ncx
+            sizes = np.diff(off[:len(coords) * per_plane + 1])
+            keep = np.nonzero(sizes > 0)[0]
+            if not len(keep):
+                continue
+            paths = []
+            made = set()
+            for k in keep.tolist():
+                i, rem = divmod(k, per_plane)
+                iy, ix = divmod(rem, ncx)
+                t, c, z = coords[i]
+                cdir = os.path.join(self.path, str(lv), str(t), str(c), str(z), str(y_off // cyf + iy))
+                if cdir not in made:
+                    os.makedirs(cdir, exist_ok=True)
+                    made.add(cdir)
+                paths.append(os.path.join(cdir, str(ix)))
+            # the kept chunks' byte ranges: frames are packed densely, empty chunks take no bytes, so consecutive kept chunks are
+            # contiguous in the buffer and [off[k], off[k + 1]) for the kept k is one non-decreasing offset list
+            starts = off[keep]
+            ends = off[keep + 1]
+            if len(keep) > 1 and not np.array_equal(starts[1:], ends[:-1]):
+                raise RuntimeError("blosc frames are not packed densely")
+            data_offsets = np.concatenate([starts, ends[-1:]]).astype(np.int64)
+            written += native.write_files(paths, frames.numpy(), data_offsets, n_threads=self._pool._max_workers)
+        return written
 
     def _check(self):
         if self._error is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SQ_VERSION 107 /* 0.1.6: sq_arena_* (canvas memory mapped over all memory classes of the card); 0.1.5: sq_selftest_normalise_divide; 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
+#define SQ_VERSION 108 /* 0.1.7: sq_write_files (chunk files by native threads); 0.1.6: sq_arena_* (canvas memory mapped over all memory classes of the card); 0.1.5: sq_selftest_normalise_divide; 0.1.4: sq_fuse_plan_create_spans / sq_fuse_plan_expand (work list of an overwrite plan produced on the device) */
 
 typedef enum sq_status {
     SQ_OK = 0,
@@ -299,6 +299,18 @@ int64_t sq_blosc_scratch_bytes(int32_t n_planes, int32_t h, int32_t w, int32_t d
 int sq_blosc_encode_planes(const void *planes_dev, int64_t plane_stride, int64_t pitch, int32_t n_planes, int32_t h, int32_t w,
                            int32_t dtype, int32_t chunk_h, int32_t chunk_w, void *scratch_dev, int64_t scratch_bytes,
                            uint64_t *offsets_dev, void *out_dev, int64_t out_capacity, uint32_t *status_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Chunk files.  The store of save_region_ome_zarr (stitcher.py:771-859; zarr v2, one file per chunk, chunks (1,1,1,512,512)) is
+ * hundreds of thousands of half-MB files per region; written one by one from the interpreter they were the wall of a files ->
+ * store run once the codec ran on the device.  sq_write_files writes n_files files from ONE host buffer with native threads:
+ * file i is the NUL-terminated string at paths + path_offsets[i] and holds data[data_offsets[i] .. data_offsets[i + 1]) (created
+ * or truncated, mode 0644; an empty range makes an empty file).  The directories must exist.  n_threads <= 0: 16.  Stops at the
+ * first failure (SQ_ERR_INVALID, the path and errno text in sq_last_error); *bytes_written = bytes that reached the files.
+ * Host-only: no device, no stream.
+ * ---------------------------------------------------------------------------------------- */
+int sq_write_files(const char *paths, const int64_t *path_offsets, const void *data, const int64_t *data_offsets, int64_t n_files,
+                   int32_t n_threads, int64_t *bytes_written);
 
 /* ------------------------------------------------------------------------------------------
  * Flatfield ESTIMATE: replaces basicpy.BaSiC(get_darkfield=False, smoothness_flatfield=s).fit(images).flatfield

@@ -3,11 +3,13 @@
  *   gcc -D__HIP_PLATFORM_AMD__ c_abi_smoke.c -I include -I /opt/rocm/include -L image-stitcher_amd/csrc
  *       -lsquidstitch -L /opt/rocm/lib -lamdhip64
  */
+#define _POSIX_C_SOURCE 200809L   /* mkstemp under -std=c11 */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "squidstitch.h"
 
@@ -91,6 +93,39 @@ int main(void) {
         sq_fuse_plan_destroy(spans);
         free(table2);
         hipFree(d_table2); hipFree(d_scratch);
+    }
+    /* the canvas in an arena (sq_arena_create: physical slices classified and mapped round-robin over the card's memory
+       classes): plain device memory to the fusion call, the same voxels; then the canvas as a chunk file by native threads */
+    {
+        sq_arena_info info;
+        memset(&info, 0, sizeof info);
+        sq_arena *arena = sq_arena_create(64 << 20, 192 << 20, 8 << 20, 32 << 20, 0, stream, &info);
+        if (!arena) { printf("arena: %s\n", sq_last_error()); return 8; }
+        if (!info.base_dev || info.bytes != (64 << 20) || info.n_slices != 8 || info.n_classes < 1 || info.n_candidates < 8) { printf("arena info\n"); return 8; }
+        sq_fuse_args c = a;
+        c.canvas_dev = (char *)info.base_dev + 4096;
+        CHECK_HIP(hipMemset(info.base_dev, 0x33, 1 << 20));
+        CHECK_SQ(sq_fuse_planes(&c, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_HIP(hipMemcpy(got, c.canvas_dev, sizeof got, hipMemcpyDeviceToHost));
+        if (memcmp(got, want, sizeof want) != 0) { printf("canvas in the arena differs\n"); return 8; }
+        sq_arena_info again;
+        CHECK_SQ(sq_arena_info_get(arena, &again));
+        if (again.base_dev != info.base_dev) { printf("arena info_get\n"); return 8; }
+        CHECK_SQ(sq_arena_destroy(arena));
+        char path[] = "/tmp/sq_c_abi_chunk_XXXXXX";
+        int fd = mkstemp(path);
+        if (fd < 0) { printf("mkstemp\n"); return 8; }
+        close(fd);
+        const int64_t poff[1] = {0}, doff[2] = {0, (int64_t)sizeof got};
+        int64_t done = 0;
+        CHECK_SQ(sq_write_files(path, poff, got, doff, 1, 2, &done));
+        FILE *fh = fopen(path, "rb");
+        static uint16_t back[HC][WC];
+        const size_t rd = fh ? fread(back, 1, sizeof back, fh) : 0;
+        if (fh) fclose(fh);
+        remove(path);
+        if (done != (int64_t)sizeof got || rd != sizeof got || memcmp(back, want, sizeof want) != 0) { printf("chunk file differs\n"); return 8; }
     }
     /* error path: a wrong canvas size must be refused with a message, not crash */
     a.canvas_w = WC + 1;

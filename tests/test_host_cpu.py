@@ -461,3 +461,28 @@ def test_dynamic_registration_is_stored_and_ignored_like_the_reference(tmp_path,
     assert called == [1]
     # without -r the extension is off whatever the flag says
     assert not Stitcher(StitchingParameters(input_folder=root), all_pairs_registration=True).all_pairs_registration
+
+
+def test_native_chunk_file_writer(tmp_path):
+    """sq_write_files (the chunk files of the OME-Zarr store, written by native threads): every file holds exactly its byte range,
+    empty ranges make empty files, existing files are replaced, a missing directory is an error that names the path."""
+    from image_stitcher_amd import native
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
+    cuts = np.sort(rng.choice(np.arange(1, data.size), size=400, replace=False))
+    offsets = np.concatenate([[0], cuts, cuts[-1:], [data.size]]).astype(np.int64)      # 402 files, one of them empty
+    for d in range(7):
+        os.makedirs(tmp_path / str(d))
+    paths = [str(tmp_path / str(i % 7) / f'chunk.{i}') for i in range(len(offsets) - 1)]
+    with open(paths[5], 'wb') as fh:
+        fh.write(b'x' * 100000)                                                          # longer than what replaces it
+    assert native.write_files(paths, data, offsets, n_threads=8) == data.size
+    for i, p in enumerate(paths):
+        with open(p, 'rb') as fh:
+            assert fh.read() == data[offsets[i]:offsets[i + 1]].tobytes(), i
+    assert os.path.getsize(paths[-2]) == 0
+    assert native.write_files([], data, np.zeros(1, np.int64)) == 0
+    with pytest.raises(native.NativeError, match='no_such_dir'):
+        native.write_files([str(tmp_path / 'no_such_dir' / 'x')], data, np.array([0, 10]))
+    with pytest.raises(ValueError):
+        native.write_files(paths[:2], data, np.array([0, 10]))                           # offsets do not match the paths

@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sq_version() == 107
+    assert L.sq_version() == 108
 
 
 def test_struct_layouts_match_header():

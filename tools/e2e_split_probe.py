@@ -5,7 +5,7 @@ store on the directory given (the box's disk) and once on /dev/shm:
     h2d       page-locked staging -> device, the copies alone (the PCIe rate the ingest could reach)      GB/s
     ingest    files -> device canvas: Stitcher.stitch_region(device_output=True) (read + H2D + fusion)    GB/s of pixels, s
     encode    pyramid levels + Blosc-1 chunk frames of the fused planes, on the device                    GB/s of pixels in
-    write     the frames -> files (what the writer threads do), from memory                               GB/s of frame bytes
+    write     the frames -> files from memory: Python's file calls, then native threads (sq_write_files)      GB/s of frame bytes
     run       files -> store, streamed (Stitcher.stream_region_to_zarr)                                   s, Gvoxel/s
     python tools/e2e_split_probe.py [dir=/tmp] [z=4]"""
 import contextlib, io, os, shutil, sys, tempfile, time
@@ -100,7 +100,18 @@ def probe(where):
             list(pool.map(put, jobs))
             os.sync()
             dt = time.time() - t0
-        print(f'[{where}] write   {len(jobs)} chunk files, {fbytes / 1e9:.2f} GB: {dt:6.2f} s  {fbytes / dt / 1e9:6.2f} GB/s (16 threads, incl. sync)', flush=True)
+        print(f'[{where}] write   {len(jobs)} chunk files, {fbytes / 1e9:.2f} GB through Python open / write / close: {dt:6.2f} s  {fbytes / dt / 1e9:6.2f} GB/s (16 threads, incl. sync)', flush=True)
+        shutil.rmtree(outdir, ignore_errors=True)
+        # the same files by native threads (sq_write_files: what the stream writer uses since round 4), one call per level
+        os.makedirs(outdir)
+        t0 = time.time()
+        for li, (buf, o) in enumerate(frames):
+            keep = np.nonzero(np.diff(o) > 0)[0]
+            if len(keep):
+                native.write_files([os.path.join(outdir, f'{li}.{i}') for i in keep.tolist()], buf, np.concatenate([o[keep], o[keep[-1] + 1:keep[-1] + 2]]), 16)
+        t1 = time.time()
+        os.sync()
+        print(f'[{where}] write   the same through sq_write_files: {t1 - t0:6.2f} s  {fbytes / (t1 - t0) / 1e9:6.2f} GB/s (16 native threads; + {time.time() - t1:.2f} s of sync)', flush=True)
         shutil.rmtree(outdir, ignore_errors=True)
         del region, planes, levels, encs, frames
         # ---- run: files -> store, streamed
