@@ -379,10 +379,14 @@ def alloc_planes(n, g, hc, wc, dev, layout):
     import torch
     from image_stitcher_amd import native
     if layout == 'mixed':
-        # the canvas FIRST, while the card is empty: the arena takes up to three times its size, classifies it, keeps a third
+        # the canvas FIRST, while the card is empty: the arena takes candidate memory chunk by chunk, classifies it, keeps a third
         # per memory class and gives the rest back (native.DeviceArena); the tiles then come from a plain allocation -- reads
         # do not depend on the class
-        arena = native.DeviceArena(native.canvas_bytes(n, hc, wc, torch.uint16), dev)
+        need = native.canvas_bytes(n, hc, wc, torch.uint16)
+        # ranks that SHARE a card (the gloo rehearsal of N ranks on one GPU) must not each reach for all of its memory while
+        # they look for a balanced arena: they take what they need and no more (the classes then are whatever comes)
+        shared_card = int(os.environ.get('WORLD_SIZE', '1')) > max(1, torch.cuda.device_count())
+        arena = native.DeviceArena(need, dev, candidate_bytes=need if shared_card else None)
         canvas = native.empty_canvas(n, hc, wc, torch.uint16, dev, arena=arena)
         ARENAS.append(arena)
         return torch.empty((n, g * g, TILE, TILE), dtype=torch.uint16, device=dev), canvas
