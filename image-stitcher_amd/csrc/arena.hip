@@ -79,19 +79,28 @@ double now_s() {
 
 struct sq_arena {
     char *base = nullptr;
-    size_t bytes = 0, slice = 0;
+    size_t bytes = 0, slice = 0;      // bytes: the RESERVED virtual range at base
+    size_t mapped_slices = 0;         // slices [0, mapped_slices) of the range are mapped, one hipMemMap each
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
-    bool mapped = false;
     sq_arena_info info{};
 };
 
 namespace {
 
+// Every mapping is undone by a hipMemUnmap of exactly ITS range: one call over a range that holds many mappings undoes the first
+// and leaves the runtime's view of the others in place -- memcpys into a range reserved later at the same address then went to
+// the slices that USED to be there while kernels (page tables) saw the new ones (found by the plain-C caller of the test suite,
+// whose arena came back at the candidates' address).
+void unmap_all(sq_arena *a) {
+    for (size_t i = 0; i < a->mapped_slices; ++i) (void)hipMemUnmap(a->base + i * a->slice, a->slice);
+    a->mapped_slices = 0;
+}
+
 void release(sq_arena *a) {
     if (!a) return;
     if (a->base) {
-        if (a->mapped) (void)hipMemUnmap(a->base, a->bytes);
+        unmap_all(a);
         (void)hipMemAddressFree(a->base, a->bytes);
     }
     for (auto h : a->handles) (void)hipMemRelease(h);
@@ -107,10 +116,10 @@ int map_in_order(sq_arena *a, const std::vector<int> &order) {
     for (size_t i = 0; i < order.size(); ++i) {
         hipError_t e = hipMemMap(a->base + i * a->slice, a->slice, 0, a->handles[order[i]], 0);
         if (e != hipSuccess) return sq::fail(SQ_ERR_HIP, "sq_arena: hipMemMap of slice %zu failed: %s", i, hipGetErrorString(e));
+        a->mapped_slices = i + 1;
+        e = hipMemSetAccess(a->base + i * a->slice, a->slice, &acc, 1);
+        if (e != hipSuccess) return sq::fail(SQ_ERR_HIP, "sq_arena: hipMemSetAccess of slice %zu failed: %s", i, hipGetErrorString(e));
     }
-    a->mapped = true;
-    hipError_t e = hipMemSetAccess(a->base, a->bytes, &acc, 1);
-    if (e != hipSuccess) return sq::fail(SQ_ERR_HIP, "sq_arena: hipMemSetAccess failed: %s", hipGetErrorString(e));
     return SQ_OK;
 }
 
@@ -163,7 +172,7 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     acc.flags = hipMemAccessFlagsProtReadWrite;
     const size_t cand_bytes = cap * slice;
     a->bytes = cand_bytes;      // (release() unmaps / frees what `bytes` says while the candidates' range exists)
-    hipError_t e = hipMemAddressReserve((void **)&a->base, cand_bytes, (size_t)1 << 30, nullptr, 0);
+    hipError_t e = hipMemAddressReserve((void **)&a->base, cand_bytes, 0, nullptr, 0);
     if (e != hipSuccess) {
         a->base = nullptr;
         sq::fail(e == hipErrorNotSupported ? SQ_ERR_UNSUPPORTED : SQ_ERR_HIP, "sq_arena_create: %shipMemAddressReserve of %zu bytes failed: %s",
@@ -281,21 +290,21 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
                          e == hipErrorNotSupported ? "virtual memory management unsupported: " : "", have + got, n, slice >> 20, hipGetErrorString(e));
                 (void)hipEventDestroy(e0);
                 (void)hipEventDestroy(e1);
-                a->mapped = have > 0;
-                a->bytes = have * slice;
-                if (a->mapped) (void)hipMemUnmap(a->base, a->bytes);
-                a->mapped = false;
-                a->bytes = cand_bytes;
-                release(a);
+                release(a);      // unmaps the slices mapped so far, frees the range, releases every handle taken
                 return nullptr;
             }
             a->handles.push_back(h);
         }
         t_create += now_s() - tc;
         tc = now_s();
-        for (size_t i = have; i < have + got && !bad; ++i)
-            if (hipMemMap(a->base + i * slice, slice, 0, a->handles[i], 0) != hipSuccess) bad = true;
-        if (!bad && got && hipMemSetAccess(a->base + have * slice, got * slice, &acc, 1) != hipSuccess) bad = true;
+        for (size_t i = have; i < have + got && !bad; ++i) {
+            if (hipMemMap(a->base + i * slice, slice, 0, a->handles[i], 0) != hipSuccess) {
+                bad = true;
+                break;
+            }
+            a->mapped_slices = i + 1;
+            if (hipMemSetAccess(a->base + i * slice, slice, &acc, 1) != hipSuccess) bad = true;
+        }
         t_map += now_s() - tc;
         have += got;
         if (natural || bad) break;
@@ -307,10 +316,9 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     const size_t ncand = have;
     auto unmap_candidates = [&]() {
         (void)hipStreamSynchronize(st);
-        if (ncand) (void)hipMemUnmap(a->base, ncand * slice);
+        unmap_all(a);
         (void)hipMemAddressFree(a->base, cand_bytes);
         a->base = nullptr;
-        a->mapped = false;
     };
     if (bad || hipGetLastError() != hipSuccess || ncand < n) {
         sq::fail(SQ_ERR_HIP, "sq_arena_create: mapping or probing the candidate slices failed");
@@ -339,8 +347,15 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     I.max_pair_gbs = (float)ghi;
     for (int c = 0; c < SQ_ARENA_MAX_CLASSES; ++c) I.class_slices[c] = I.class_candidates[c] = 0;
     for (size_t s = 0; s < ncand; ++s) I.class_candidates[class_of_slice(s)]++;
-    unmap_candidates();
-    if (trace_on()) fprintf(stderr, "[sq_arena] unmap + free of the candidates' range: %.1f ms\n", (now_s() - tp) * 1e3);
+    // The candidates are unmapped here, but their RANGE stays reserved until the arena's own range has been reserved: the arena
+    // must not come back at an address the candidates were mapped at.  (Seen with the plain-C caller of the test suite under
+    // ROCm 7.2's runtime: the arena was given the candidates' address, kernels and small copies saw the new mapping, a 120-KB
+    // hipMemcpy to the host still read the slice that USED to be there.)
+    (void)hipStreamSynchronize(st);
+    unmap_all(a);
+    char *cand_base = a->base;
+    a->base = nullptr;
+    if (trace_on()) fprintf(stderr, "[sq_arena] unmap of the candidates: %.1f ms\n", (now_s() - tp) * 1e3);
     tp = now_s();
     std::vector<int> chosen;
     chosen.reserve(n);
@@ -377,7 +392,8 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     if (trace_on()) fprintf(stderr, "[sq_arena] release of %zu slices: %.1f ms\n", ncand - n, (now_s() - tp) * 1e3);
     tp = now_s();
     a->bytes = n * slice;
-    e = hipMemAddressReserve((void **)&a->base, a->bytes, (size_t)1 << 30, nullptr, 0);
+    e = hipMemAddressReserve((void **)&a->base, a->bytes, 0, nullptr, 0);
+    (void)hipMemAddressFree(cand_base, cand_bytes);
     if (e != hipSuccess) {
         a->base = nullptr;
         sq::fail(SQ_ERR_HIP, "sq_arena_create: hipMemAddressReserve of %zu bytes failed: %s", a->bytes, hipGetErrorString(e));

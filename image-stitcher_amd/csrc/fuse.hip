@@ -944,7 +944,11 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             const int v = lane + 64 * k;
             const bool act = v >= v_first && v < v_end;
             const int p0 = v * VEC - mis;
-            const uint32_t o = (uint32_t)min(max(p0, 0), n - VEC);   // clamped: v_end > v_first implies n >= VEC; == p0 where act
+            // Lanes without a vector of their own load the row's first / last WHOLE vector (their store is masked): no source line is
+            // touched that the row's own vectors do not touch.  Clamping to the row's first / last PIXELS instead (rounds 1-3) made
+            // every LEAVE_TAIL item fetch the source line its neighbour owns, and every row the line before its first vector:
+            // 26.52 -> 26.25 ms per 40-plane launch of config 3 (0.7235 -> 0.7307), profiles/r04_exp_clamp_inside.log.
+            const uint32_t o = (uint32_t)min(max(p0, v_first * VEC - mis), (v_end - 1) * VEC - mis);
             GT g[8], rc[8];
             if constexpr (GAINS) load_gains(frow + o * GSZ, g);
             u32x4 px[ZB];

@@ -108,7 +108,24 @@ int main(void) {
         CHECK_SQ(sq_fuse_planes(&c, stream));
         CHECK_HIP(hipStreamSynchronize(stream));
         CHECK_HIP(hipMemcpy(got, c.canvas_dev, sizeof got, hipMemcpyDeviceToHost));
-        if (memcmp(got, want, sizeof want) != 0) { printf("canvas in the arena differs\n"); return 8; }
+        if (memcmp(got, want, sizeof want) != 0) {
+            uint32_t w0[4], w1[4];
+            hipMemcpy(w0, info.base_dev, 16, hipMemcpyDeviceToHost);
+            hipMemcpy(w1, (char *)info.base_dev + 4096 + sizeof got + 64, 16, hipMemcpyDeviceToHost);
+            uint16_t s16[8];
+            hipMemcpy(s16, c.canvas_dev, 16, hipMemcpyDeviceToHost);
+            static uint16_t again[HC][WC];
+            hipMemcpy(again, c.canvas_dev, sizeof again, hipMemcpyDeviceToHost);
+            printf("16-byte read of the canvas start: %u %u %u %u; second full read: %u %u %u %u (%s the first)\n", s16[0], s16[1], s16[2], s16[3],
+                   again[0][0], again[0][1], again[0][2], again[0][3], memcmp(again, got, sizeof got) ? "differs from" : "equals");
+            printf("arena base %p (%lld bytes, %d slices of %d candidates, %d classes), canvas %p; base holds %08x %08x, behind the canvas %08x %08x\n",
+                   info.base_dev, (long long)info.bytes, info.n_slices, info.n_candidates, info.n_classes, c.canvas_dev, w0[0], w0[1], w1[0], w1[1]);
+            int shown = 0;
+            for (int y = 0; y < HC && shown < 4; ++y)
+                for (int x = 0; x < WC && shown < 4; ++x)
+                    if (got[y][x] != want[y][x]) printf("canvas in the arena differs at (%d, %d): %u, expected %u\n", y, x, got[y][x], want[y][x]), ++shown;
+            return 8;
+        }
         sq_arena_info again;
         CHECK_SQ(sq_arena_info_get(arena, &again));
         if (again.base_dev != info.base_dev) { printf("arena info_get\n"); return 8; }

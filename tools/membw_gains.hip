@@ -715,7 +715,7 @@ int main(int argc, char **argv) {
         // remap round-robin over the classes, slice by slice
         CK(hipDeviceSynchronize());
         t0 = now();
-        CK(hipMemUnmap(va, (size_t)n * SLICE));
+        for (int i = 0; i < n; ++i) CK(hipMemUnmap(va + (size_t)i * SLICE, SLICE));      // one call per mapping (a call over many undoes the first only)
         int no = 0;
         if (natural) {
             for (int i = 0; i < n; ++i) order[no++] = i;
