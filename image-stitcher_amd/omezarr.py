@@ -331,7 +331,7 @@ class PlaneStreamWriter:
 
     def __init__(self, path: str, shapes: Sequence[tuple], dtype, *, chunks=(1, 1, 1, 512, 512), batch: int = 1,
                  compression: str = 'zlib', level: int = 1, device='cuda:0', workers: Optional[int] = None, slots: int = 2,
-                 buffers=None, row_offset: int = 0, level_heights: Optional[Sequence[int]] = None):
+                 buffers=None, row_offset: int = 0, level_heights: Optional[Sequence[int]] = None, canvas_arena=None):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -350,7 +350,9 @@ class PlaneStreamWriter:
         self._blosc = compression == 'blosc'
         if buffers is None:
             # level 0 = the fusion canvas: dense rows, planes on 128-byte lines (native.empty_canvas)
-            dev = [[native.empty_canvas(self.batch, s[0], s[1], tdtype, device) if lv == 0 else
+            # (canvas_arena: a native.DeviceArena to carve the level-0 canvases from -- memory mapped over all memory classes of
+            #  the card, where the fusion kernel writes fastest; the slot tensors keep it alive)
+            dev = [[native.empty_canvas(self.batch, s[0], s[1], tdtype, device, arena=canvas_arena) if lv == 0 else
                     torch.empty((self.batch,) + s, dtype=tdtype, device=device) for lv, s in enumerate(yx)] for _ in range(slots)]
             if self._blosc:
                 # chunks are encoded on the device (csrc/blosc.hip): the host mirrors hold packed FRAMES, not planes

@@ -561,6 +561,27 @@ class Stitcher:
                                                            expand_on_device=len(rects) >= 64)
         return plan
 
+    def _new_arena(self, need: int):
+        """A DeviceArena of ``need`` bytes, or None when the canvas has to come from a plain allocation: the platform lacks
+        virtual memory management (remembered), or the card cannot give the slices even after PyTorch's cached blocks have been
+        handed back (this call only).  Anything else raises."""
+        import torch
+        for attempt in range(2):
+            try:
+                return native.DeviceArena(need, self.device)
+            except native.NativeError as exc:
+                if 'virtual memory management unsupported' in str(exc):
+                    print(f"[canvas] no virtual memory management on this platform ({exc}); the canvas comes from a plain allocation")
+                    self._arena_unsupported = True
+                    return None
+                if 'out of memory' not in str(exc).lower():
+                    raise
+                if attempt == 0:
+                    torch.cuda.empty_cache()      # blocks PyTorch's allocator holds but nobody uses
+                else:
+                    print(f"[canvas] the card cannot give {need / 2**30:.1f} GiB of arena slices ({exc}); the canvas comes from a plain allocation")
+        return None
+
     def _empty_canvas(self, n_planes, hc, wc, tdtype):
         """The canvas of ``stitch_planes`` ([n_planes, hc, wc], planes on 128-byte lines, never zero-filled: stitcher.py:356-362's
         da.zeros is written by the fusion kernel).  From ``canvas_arena_min_bytes`` up it is carved from a DeviceArena --
@@ -575,14 +596,8 @@ class Stitcher:
         if self._arena is None or busy or self._arena.nbytes < need:
             if self._arena is not None and not busy:
                 self._arena.close()
-            self._arena = None
-            try:
-                self._arena = native.DeviceArena(need, self.device)
-            except native.NativeError as exc:
-                if 'virtual memory management unsupported' not in str(exc):
-                    raise
-                print(f"[canvas] no virtual memory management on this platform ({exc}); the canvas comes from a plain allocation")
-                self._arena_unsupported = True
+            self._arena = self._new_arena(need)
+            if self._arena is None:
                 return native.empty_canvas(n_planes, hc, wc, tdtype, self.device)
             self.canvas_arena_info = self._arena.info
             print(f"[canvas] arena of {self._arena.nbytes / 2**30:.1f} GiB over {self._arena.info['n_classes']} memory classes "
@@ -859,10 +874,18 @@ class Stitcher:
 
         def make_writer(batch):
             key = ('writer', tuple(tuple(s[3:]) for s in shapes), batch, np.dtype(self.dtype).str)
+            cached = self._buffer_cache.get(key)
+            arena = None
+            if cached is None and not self._arena_unsupported:
+                # the writer's two slots of level-0 canvases are what the fusion kernel writes on this path: from an arena too
+                # (it lives as long as the slot tensors, i.e. with the cached buffers)
+                need = 2 * native.canvas_bytes(batch, shapes[0][3], shapes[0][4], native.torch_dtype_of(self.dtype))
+                if need >= self.canvas_arena_min_bytes:
+                    arena = self._new_arena(need)
             made.append(omezarr.PlaneStreamWriter(output_path, shapes, self.dtype, chunks=self.chunks or (1, 1, 1, 512, 512),
                                                   batch=batch, compression=self.zarr_compression, device=self.device,
-                                                  buffers=self._buffer_cache.get(key), row_offset=row_offset,
-                                                  level_heights=level_heights))
+                                                  buffers=cached, row_offset=row_offset,
+                                                  level_heights=level_heights, canvas_arena=arena))
             self._keep_buffers(key, made[-1].buffers)
             return made[-1]
 

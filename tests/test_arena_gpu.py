@@ -156,3 +156,52 @@ def test_plane_groups_into_an_arena_canvas_equal_the_oracle(seed):
     assert bool((raw[stride_b * n_planes:] == 0xA5).all())
     del raw, canvas, guard
     arena.close()
+
+
+def test_streamed_run_fuses_into_arena_canvases(tmp_path, monkeypatch):
+    """Stitcher.run() with .ome.zarr output (the CLI's default path) fuses into the stream writer's two slot canvases; with the
+    arena forced on they are carved from a DeviceArena too.  The stores are the reference's canvases, and a card that cannot give
+    the slices falls back to a plain allocation instead of failing."""
+    torch = _torch()
+    from image_stitcher_amd import omezarr
+    from image_stitcher_amd.stitcher import Stitcher
+    from image_stitcher_amd.stitcher_parameters import StitchingParameters
+    info, arrays = load_case('reg_multi')
+    root = str(tmp_path / 'acq')
+    synth.write_acquisition(spec_of(info), root)
+    monkeypatch.setenv('SQ_CANVAS_ARENA_MIN_BYTES', '1')
+    made = []
+    real = native.DeviceArena
+
+    class Counting(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(native, 'DeviceArena', Counting)
+    st = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    st.run()
+    assert len(made) == 1, "one arena for the writer's slots, reused for every region of the same geometry"
+    for key in info['canvases']:
+        t, region = key[1:].split('_', 1)
+        store = os.path.join(st.output_folder, f'{t}_stitched', f'{region}_stitched.ome.zarr')
+        np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
+    # the card "cannot give the slices": a plain allocation, the same stores
+    def refusing(*a, **k):
+        raise native.NativeError("sq_arena_create(1 bytes) failed: sq_arena_create: hipMemCreate of slice 0 of 1 (64 MiB each) failed: out of memory")
+    monkeypatch.setattr(native, 'DeviceArena', refusing)
+    st2 = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    st2.run()
+    key = list(info['canvases'])[0]
+    t, region = key[1:].split('_', 1)
+    store = os.path.join(st2.output_folder, f'{t}_stitched', f'{region}_stitched.ome.zarr')
+    np.testing.assert_array_equal(omezarr.read_array(os.path.join(store, '0')), arrays[f'{key}_canvas'])
+    assert not st2._arena_unsupported       # out of memory is not "unsupported": the next region may try again
+    # ... while a platform without virtual memory management is remembered
+    def unsupported(*a, **k):
+        raise native.NativeError("sq_arena_create failed: sq_arena_create: virtual memory management unsupported: hipMemCreate ...")
+    monkeypatch.setattr(native, 'DeviceArena', unsupported)
+    st3 = Stitcher(StitchingParameters(input_folder=root, use_registration=True), normalization=None)
+    st3.get_timepoints(); st3.extract_acquisition_parameters(); st3.get_pixel_size(); st3.parse_acquisition_metadata()
+    st3.calculate_shifts(st3.timepoints[0], st3.regions[0])
+    np.testing.assert_array_equal(st3.stitch_region(int(t), region), arrays[f'{key}_canvas'])
+    assert st3._arena_unsupported and st3._arena is None

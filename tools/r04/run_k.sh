@@ -14,3 +14,8 @@ pass fetch FETCH_SIZE && pass write WRITE_SIZE && pass sq1 SQ_INSTS_VALU SQ_WAIT
 cat $O/feather_counters.log
 find $O -name "*_kernel_stats.csv" | head -3
 find $O -name "*kernel_trace.csv" -size +5M -delete
+# the headline job's resident batch (10 planes of the 32 x 32 grid): FETCH_SIZE / WRITE_SIZE passes for profiles/pmc_traffic_cfg4_batch.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/cfg4_pmc_$c -o run -- python3 bench.py --workload cfg4 --planes 20 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/cfg4_pmc_$c.err || { echo "cfg4 pmc $c failed"; tail -5 $O/cfg4_pmc_$c.err; exit 1; }
+done
+python3 tools/pmc_traffic.py $O/cfg4_pmc_FETCH_SIZE $O/cfg4_pmc_WRITE_SIZE cfg4 10 "round 4 last build: one resident batch of the headline job, 10 planes of the 32x32 grid, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of bench.py --workload cfg4 --planes 20 --steps 1 --warmup 1 --no-cpu-baseline" $O/pmc_traffic_cfg4_batch.json
