@@ -831,6 +831,18 @@ __device__ __forceinline__ uint32_t quot_pair(uint32_t word, G g_lo, G g_hi, G r
     const u16x2 p = __builtin_amdgcn_cvt_pk_u16(a, b);
     return (uint32_t)p[0] | ((uint32_t)p[1] << 16);
 }
+// four uint8 pixels of one 32-bit word (uint8 planes in groups, round 4): the same quotient -- the exhaustive proof of the
+// shortened divide covers every numerator below 65536 -- clipped to 255 and packed
+template <int RND, typename G>
+__device__ __forceinline__ uint32_t quot_quad(uint32_t word, const G *g, const G *r) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const G n = (G)((word >> (8 * k)) & 0xFFu);
+        out |= min(cvt_u32_sat(quot_of<RND>(n, g[k], r[k])), 255u) << (8 * k);
+    }
+    return out;
+}
 // 8 consecutive gains at any alignment
 __device__ __forceinline__ void load_gains(const char *p, float (&g)[8]) {
     const f32x4 a = ldg<F32x4U>(p), b = ldg<F32x4U>(p + 16);
@@ -849,6 +861,19 @@ __device__ __forceinline__ void load_gains(const char *p, double (&g)[8]) {
     }
 }
 
+// 16 consecutive gains (a uint8 plane's 16-byte pixel vector)
+template <typename GT>
+__device__ __forceinline__ void load_gains(const char *p, GT (&g)[16]) {
+    GT lo[8], hi[8];
+    load_gains(p, lo);
+    load_gains(p + 8 * sizeof(GT), hi);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        g[e] = lo[e];
+        g[8 + e] = hi[e];
+    }
+}
+
 // (One row per workgroup -- wave w taking slot w, 2 + ZB loads and ZB stores per thread -- launched one-shot, the regime
 // in which a bare copy gains 10 %, was built and measured with groups of 5 / 3 / 2: 0.53 / 0.43 / 0.39 against 0.62-0.64
 // for this form on the same box; the descriptor, its LDS hand-over and the tile pointers cost more per 14-36 KB workgroup
@@ -857,17 +882,19 @@ __device__ __forceinline__ void load_gains(const char *p, double (&g)[8]) {
 // geometry, yet five planes per thread write faster than one plane per launch when the planes lie in different stretches
 // of device memory (DESIGN.md 5.1 point 9: the bare 5-plane copy 0.72-0.75 of peak against 0.64-0.65 plane by plane)
 struct NoGain {};
-template <bool FULL, int RND = 0, typename G = float>
+// T = uint8_t (round 4): the same row loop with 16 pixels per lane and slot and 128 pixels per line.  uint8 planes have no seam
+// owners (a line is 128 pixels, two per lane in the whole-line pass: not built) -- the kernel ignores the plan's seam records for
+// the whole plane, which is a partition of the canvas like honouring them for the whole plane is.
+template <bool FULL, int RND = 0, typename G = float, typename T = uint16_t>
 __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it,
                                                 const int wave, const int lane) {
-    typedef uint16_t T;
     constexpr bool GAINS = !std::is_same<G, NoGain>::value;
     typedef typename std::conditional<GAINS, G, float>::type GT;      // the arithmetic type where there is arithmetic
-    constexpr uint32_t GSZ = sizeof(GT);
-    constexpr int VEC = 8, LINE = 64;
+    constexpr uint32_t GSZ = sizeof(GT), TSZ = sizeof(T), TMAX = sizeof(T) == 1 ? 255u : 65535u;
+    constexpr int VEC = 16 / (int)sizeof(T), LINE = 128 / (int)sizeof(T);
     constexpr int SLOTS = BLOCK_COLS / VEC / 64 + 1;
     const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
-    const int sflags = sgpr(A.seam.flags);
+    const int sflags = sizeof(T) == 2 ? sgpr(A.seam.flags) : 0;
     const bool leave_tail = sflags & SEAM_LEAVE_TAIL;
     T *cplane[ZB];
     const T *tiles[ZB];
@@ -898,11 +925,11 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                 for (int z = 0; z < ZB; ++z)
                     if (FULL || z < gn) {
                         const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
-                        const T e = ldg_s<T>(reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc) + po * 2);
+                        const T e = ldg_s<T>(reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc) + po * (int)TSZ);
                         uint32_t kq = e;
-                        if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e, eg, er)), 65535u);
+                        if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e, eg, er)), TMAX);
                         if (!left) kq = 0u;
-                        stg_s<T>(reinterpret_cast<char *>(cplane[z] + doff) + p * 2, (T)kq);
+                        stg_s<T>(reinterpret_cast<char *>(cplane[z] + doff) + p * (int)TSZ, (T)kq);
                     }
             }
 #pragma unroll
@@ -949,15 +976,15 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             // every LEAVE_TAIL item fetch the source line its neighbour owns, and every row the line before its first vector:
             // 26.52 -> 26.25 ms per 40-plane launch of config 3 (0.7235 -> 0.7307), profiles/r04_exp_clamp_inside.log.
             const uint32_t o = (uint32_t)min(max(p0, v_first * VEC - mis), (v_end - 1) * VEC - mis);
-            GT g[8], rc[8];
+            GT g[VEC], rc[VEC];
             if constexpr (GAINS) load_gains(frow + o * GSZ, g);
             u32x4 px[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
-                if (FULL || z < gn) px[z] = ldg<U32x4U>(srow[z] + o * 2u);
+                if (FULL || z < gn) px[z] = ldg<U32x4U>(srow[z] + o * TSZ);
             if constexpr (GAINS) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rc[c] = recip_of<RND>(g[c]);
+                for (int c = 0; c < VEC; ++c) rc[c] = recip_of<RND>(g[c]);
             }
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
@@ -965,9 +992,12 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                     u32x4 ov = px[z];
                     if constexpr (GAINS) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) ov[c] = quot_pair<RND, GT>(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                        for (int c = 0; c < 4; ++c) {
+                            if constexpr (sizeof(T) == 2) ov[c] = quot_pair<RND, GT>(px[z][c], g[2 * c], g[2 * c + 1], rc[2 * c], rc[2 * c + 1]);
+                            else ov[c] = quot_quad<RND, GT>(px[z][c], &g[4 * c], &rc[4 * c]);
+                        }
                     }
-                    if (act) stg_nt_at(drow[z], o * 2u, ov);
+                    if (act) stg_nt_at(drow[z], o * TSZ, ov);
                 }
         }
         if (head_line) {
@@ -988,16 +1018,16 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
                 if (FULL || z < gn) {
                     const T *lt = sgpr(static_cast<const T *>(A.ltile[z]));
                     const char *lrow = lzero ? srow[z] : reinterpret_cast<const char *>(lt + (int64_t)(sb + r) * P.tile_pitch + sc);
-                    e[z] = ldg_s<T>((left ? lrow : srow[z]) + po * 2);
+                    e[z] = ldg_s<T>((left ? lrow : srow[z]) + po * (int)TSZ);
                 }
             if constexpr (GAINS) er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
                     uint32_t kq = e[z];
-                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), 65535u);
+                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), TMAX);
                     if (left && lzero) kq = 0;
-                    stg_s<T>(drow[z] + p * 2, (T)kq);
+                    stg_s<T>(drow[z] + p * (int)TSZ, (T)kq);
                 }
         }
         // the row's other edges (canvas pixels before the first / after the last whole 16-byte vector that no seam line
@@ -1018,14 +1048,14 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
             T e[ZB];
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
-                if (FULL || z < gn) e[z] = ldg_s<T>(srow[z] + eo * 2u);
+                if (FULL || z < gn) e[z] = ldg_s<T>(srow[z] + eo * TSZ);
             if constexpr (GAINS) er = recip_of<RND>(eg);
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) {
                     uint32_t kq = e[z];
-                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), 65535u);
-                    if (ep >= 0) stg_s<T>(drow[z] + eo * 2u, (T)kq);
+                    if constexpr (GAINS) kq = min(cvt_u32_sat(quot_of<RND>((GT)e[z], eg, er)), TMAX);
+                    if (ep >= 0) stg_s<T>(drow[z] + eo * TSZ, (T)kq);
                 }
         }
     }
@@ -1034,9 +1064,8 @@ __device__ __forceinline__ void process_item_zg(const FuseParams &P, const UnitA
 #ifndef SQ_WAVES_ZG
 #define SQ_WAVES_ZG 1
 #endif
-template <typename G, bool DYN>
+template <typename G, bool DYN, typename T = uint16_t>
 __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(const FuseParams P, const int64_t n_items) {
-    typedef uint16_t T;
     constexpr int FLAT = std::is_same<G, NoGain>::value ? 0 : (sizeof(G) == 8 ? 2 : 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1059,9 +1088,9 @@ __global__ __launch_bounds__(256, SQ_WAVES_ZG) void fuse_overwrite_zg_kernel(con
             process_item<T, FLAT>(P, sgpr(A.g.plane[0]), it, sgpr(static_cast<const T *>(A.tile[0])), wave, lane, sgpr(A.seam),
                                   sgpr(static_cast<const T *>(A.ltile[0])));
         } else if (gn == ZB) {
-            process_item_zg<true, 0, G>(P, A, gn, it, wave, lane);
+            process_item_zg<true, 0, G, T>(P, A, gn, it, wave, lane);
         } else {
-            process_item_zg<false, 0, G>(P, A, gn, it, wave, lane);
+            process_item_zg<false, 0, G, T>(P, A, gn, it, wave, lane);
         }
     };
     if (DYN) {
@@ -2203,23 +2232,31 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
         if (P.queue) return launch(fuse_overwrite_kernel<T, F, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);     \
         return launch(fuse_overwrite_kernel<T, F, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                 \
     } while (0)
-        if (u16 && flat && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
+        const int64_t esz = u16 ? 2 : 1;
+        if (flat && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
             // planes that share a gain image go through the items together (fuse_overwrite_zg_kernel)
             char *sc = static_cast<char *>(a->scratch_dev);
             uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
             PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
             hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, a->flat_ptrs_dev, P.flat_class, 1u, a->n_planes,
-                               a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                               a->canvas_plane_stride * esz, ZB, n_groups, groups,
                                (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
             P.groups = groups;
             P.n_groups = n_groups;
-            if (flat == 2) {
-                if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<double, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-                return launch_zg(fuse_overwrite_zg_kernel<double, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+#define SQ_ZG(G, T)                                                                                                                  \
+    do {                                                                                                                              \
+        if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<G, true, T>, P, h.n_items, a->n_planes, stream, a->grid_blocks);       \
+        return launch_zg(fuse_overwrite_zg_kernel<G, false, T>, P, h.n_items, a->n_planes, stream, a->grid_blocks);                   \
+    } while (0)
+            if (u16) {
+                if (flat == 2) SQ_ZG(double, uint16_t);
+                SQ_ZG(float, uint16_t);
             }
-            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<float, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-            return launch_zg(fuse_overwrite_zg_kernel<float, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            if (flat == 2) SQ_ZG(double, uint8_t);      // uint8 planes in groups (round 4; no seam owners: see process_item_zg)
+            SQ_ZG(float, uint8_t);
         }
+        // (uint8 planes without gains stay with the per-plane pipeline: 0.651 against 0.643 through the groups on the arena,
+        //  profiles/r04_exp_uint8_plane_groups.log -- with gains the groups take them from 0.367 to 0.601)
         if (u16 && !flat && a->scratch_dev && a->n_planes > 1 && ZB > 1 && !(a->flags & SQ_FUSE_NO_PLANE_GROUPS)) {
             // no flatfield: the planes still go through the items ZB at a time, dealt over the canvas allocation -- they
             // share nothing but the geometry, but a group's stores land in different stretches of device memory
@@ -2227,12 +2264,12 @@ extern "C" int sq_fuse_planes(const sq_fuse_args *a, void *stream_) {
             uint32_t *n_groups = reinterpret_cast<uint32_t *>(sc + SL.n_groups);
             PlaneGroup *groups = reinterpret_cast<PlaneGroup *>(sc + SL.groups);
             hipLaunchKernelGGL(build_groups_kernel, dim3(1), dim3(256), 0, stream, (const void *const *)nullptr, (const uint32_t *)nullptr, 0u,
-                               a->n_planes, a->canvas_plane_stride * (int64_t)sizeof(uint16_t), ZB, n_groups, groups,
+                               a->n_planes, a->canvas_plane_stride * esz, ZB, n_groups, groups,
                                (a->flags & SQ_FUSE_CONSECUTIVE_GROUPS) != 0);
             P.groups = groups;
             P.n_groups = n_groups;
-            if (P.queue) return launch_zg(fuse_overwrite_zg_kernel<NoGain, true>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
-            return launch_zg(fuse_overwrite_zg_kernel<NoGain, false>, P, h.n_items, a->n_planes, stream, a->grid_blocks);
+            SQ_ZG(NoGain, uint16_t);
+#undef SQ_ZG
         }
         if (u16) {
             if (flat == 0) SQ_OVERWRITE(uint16_t, 0);

@@ -484,6 +484,67 @@ def test_plane_groups_on_line_aligned_canvases(seed, mode, queues):
         np.testing.assert_array_equal(consecutive[p].cpu().numpy(), want, err_msg=f'plane {p}, groups of consecutive planes')
 
 
+@pytest.mark.parametrize('gdtype', [np.float32, np.float64, None], ids=['f32', 'f64', 'nogain'])
+@pytest.mark.parametrize('queues', [False, True], ids=['static', 'queues'])
+@pytest.mark.parametrize('seed', range(4))
+def test_uint8_planes_go_through_plane_groups(seed, queues, gdtype):
+    """uint8 tiles (output dtype = input dtype, stitcher.py:228,362) through the plane groups (round 4): 16 pixels per lane and
+    slot, the gains of a channel loaded once for up to five planes.  Registered-grid geometry wide enough for seam records (which
+    a uint8 plane ignores as a whole: both neighbours write their part of a seam's line), 2..12 planes on 1..3 gain images (one
+    holding a zero: the generic divide, groups of one) or none, canvas planes on 128-byte lines at an odd pitch: every voxel equals
+    the oracle (truncation and the clip at 255 included), the per-plane kernel gives the same, the padding keeps its poison."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(8100 + seed)
+    th, tw = int(rng.integers(24, 80)), int(rng.integers(150, 420))
+    rows, cols = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+    oy, ox = int(rng.integers(2, th // 3)), int(rng.integers(4, tw // 5))
+    n = rows * cols
+    rects = np.zeros((n, 6), dtype=np.int64)
+    for r in range(rows):
+        for c in range(cols):
+            top, left = (oy // 2 if r else 0), (ox // 2 if c else 0)
+            bottom, right = (oy // 2 if r < rows - 1 else 0), (ox // 2 if c < cols - 1 else 0)
+            rects[r * cols + c] = (top, left, th - top - bottom, tw - left - right, r * (th - oy) + top + c * 2, c * (tw - ox) + left + (rows - 1 - r) * 3)
+    ch = int(rects[:, 4].max() + th + rng.integers(0, 9))
+    cw = int(rects[:, 5].max() + tw + rng.integers(0, 9))
+    planes = int(rng.integers(2, 13))
+    tiles = rng.integers(0, 256, size=(planes, n, th, tw)).astype(np.uint8)
+    flats = which = gains = None
+    if gdtype is not None:
+        gains = [np.exp(rng.normal(-0.3, 0.6, size=(th, tw))).astype(gdtype) for _ in range(3)]      # many quotients above 255: the clip
+        gains[2][rng.integers(0, th), rng.integers(0, tw)] = 0.0
+        which = [int(rng.integers(0, 3)) if rng.random() > 0.1 else -1 for _ in range(planes)]
+        if planes >= 7:
+            which[:6] = [0] * 6
+        d_gains = [torch.from_numpy(g).to(dev) for g in gains]
+        flats = [None if k < 0 else d_gains[k] for k in which]
+        if not any(f is not None for f in flats):
+            flats = None
+    plan = native.FusePlan(rects, th, tw, ch, cw, native.SQ_FUSE_OVERWRITE)
+    d_tiles = torch.from_numpy(tiles).to(dev)
+    flags = native.SQ_FUSE_FORCE_QUEUES if queues else native.SQ_FUSE_FORCE_STATIC
+    grouped = native.empty_canvas(planes, ch, cw, torch.uint8, dev)
+    stride = grouped.stride(0)
+    assert stride % 128 == 0
+    backing = torch.full((planes * stride + 256,), 0x5A, dtype=torch.uint8, device=dev)
+    grouped = backing[128:128 + planes * stride].as_strided((planes, ch, cw), (stride, cw, 1))
+    single = native.empty_canvas(planes, ch, cw, torch.uint8, dev)
+    native.fuse_planes(plan, d_tiles, grouped, flats, flags=flags)
+    native.fuse_planes(plan, d_tiles, single, flats, flags=flags | native.SQ_FUSE_NO_PLANE_GROUPS)
+    torch.cuda.synchronize()
+    for p in range(planes):
+        g = None if (which is None or which[p] < 0) else gains[which[p]]
+        want = O.fuse_plane_overwrite(list(tiles[p]), rects, ch, cw, g)
+        assert want.dtype == np.uint8
+        np.testing.assert_array_equal(grouped[p].cpu().numpy(), want, err_msg=f'plane {p} of {planes} through the groups')
+        np.testing.assert_array_equal(single[p].cpu().numpy(), want, err_msg=f'plane {p} through the per-plane kernel')
+    host = backing.cpu().numpy()
+    assert (host[:128] == 0x5A).all() and (host[128 + planes * stride:] == 0x5A).all()
+    for p in range(planes):
+        assert (host[128 + p * stride + ch * cw:128 + (p + 1) * stride] == 0x5A).all(), f'padding behind plane {p}'
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('gdtype', [np.float32, np.float64, None], ids=['f32', 'f64', 'nogain'])
 @pytest.mark.parametrize('queues', [False, True], ids=['static', 'queues'])
