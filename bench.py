@@ -629,8 +629,9 @@ def run_region(ctx):
         out['cpu_baseline'], check = cpu_baseline(tiles, flat_list, order, spec, xs, ys, g, hc, wc, truth, canvas_of_plane)
         out['cpu_baseline_reference'] = REFERENCE_TIMING
         out['parity'].update(check)
-    want_feather = args.fusion_mode == 'feather' or (world == 1 and args.workload is None and not args.planes and not args.no_feather
-                                                     and not os.environ.get('SQ_BENCH_PMC_CHILD'))
+    # (one GPU only: under several ranks the others would sit in the closing collectives while rank 0 blends)
+    want_feather = world == 1 and (args.fusion_mode == 'feather' or (args.workload is None and not args.planes and not args.no_feather
+                                                                     and not os.environ.get('SQ_BENCH_PMC_CHILD')))
     if want_feather and rank == 0:
         out['feather'] = feather_leg(args, dev, g, hc, wc, n_planes, order, order_rc, state['shifts'], tiles, canvas, canvas_of_plane,
                                      plane_of_slot, ptrs, flat_list, slot_flats, flat_ptrs, check=not args.no_cpu_baseline)

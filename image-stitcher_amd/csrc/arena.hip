@@ -421,7 +421,14 @@ extern "C" int sq_arena_info_get(const sq_arena *arena, sq_arena_info *info) {
 
 extern "C" int sq_arena_destroy(sq_arena *arena) {
     if (!arena) return SQ_OK;
-    (void)hipDeviceSynchronize();      // nothing may still be writing into memory that is about to be unmapped
+    // nothing may still be writing into memory that is about to be unmapped: wait for the ARENA's device, whichever device is
+    // current on the calling thread (a process that drives several GPUs), and put the caller's device back
+    int current = -1;
+    (void)hipGetDevice(&current);
+    const int device = arena->device;
+    if (current != device) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
     release(arena);
+    if (current >= 0 && current != device) (void)hipSetDevice(current);
     return SQ_OK;
 }
