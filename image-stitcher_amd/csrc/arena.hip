@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <ctime>
 #include <map>
@@ -81,6 +82,7 @@ struct sq_arena {
     char *base = nullptr;
     size_t bytes = 0, slice = 0;      // bytes: the RESERVED virtual range at base
     size_t mapped_slices = 0;         // slices [0, mapped_slices) of the range are mapped, one hipMemMap each
+    bool ever_mapped = false;         // the range at base has held a mapping (it is retired, not freed: retire_range)
     int device = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     sq_arena_info info{};
@@ -92,6 +94,20 @@ namespace {
 // and leaves the runtime's view of the others in place -- memcpys into a range reserved later at the same address then went to
 // the slices that USED to be there while kernels (page tables) saw the new ones (found by the plain-C caller of the test suite,
 // whose arena came back at the candidates' address).
+// A virtual range that has held mappings is RETIRED, never freed: its reservation stays for the life of the process (address
+// space only -- the physical slices go back to the driver).  An address that has been mapped once must not be mapped again, by a
+// later arena or by anyone the driver might hand the range to: the copy engines kept translating such addresses to the slices
+// that USED to be there (kernels saw the new ones) -- a 130-KB device-to-host copy of a freshly fused canvas came back as the
+// zeros of an earlier arena's memory (tests/test_arena_gpu.py after the full-size tests in one process; the plain-C caller
+// under ROCm 7.2's runtime).  A create reserves at most the candidates' cap plus the arena itself (a few hundred GiB of the
+// 128 TiB of address space).
+std::atomic<long long> g_retired_bytes{0};
+void retire_range(char *base, size_t bytes, bool was_mapped) {
+    if (!base) return;
+    if (was_mapped) g_retired_bytes.fetch_add((long long)bytes, std::memory_order_relaxed);
+    else (void)hipMemAddressFree(base, bytes);
+}
+
 void unmap_all(sq_arena *a) {
     for (size_t i = 0; i < a->mapped_slices; ++i) (void)hipMemUnmap(a->base + i * a->slice, a->slice);
     a->mapped_slices = 0;
@@ -101,7 +117,7 @@ void release(sq_arena *a) {
     if (!a) return;
     if (a->base) {
         unmap_all(a);
-        (void)hipMemAddressFree(a->base, a->bytes);
+        retire_range(a->base, a->bytes, a->ever_mapped);
     }
     for (auto h : a->handles) (void)hipMemRelease(h);
     (void)hipGetLastError();
@@ -117,6 +133,7 @@ int map_in_order(sq_arena *a, const std::vector<int> &order) {
         hipError_t e = hipMemMap(a->base + i * a->slice, a->slice, 0, a->handles[order[i]], 0);
         if (e != hipSuccess) return sq::fail(SQ_ERR_HIP, "sq_arena: hipMemMap of slice %zu failed: %s", i, hipGetErrorString(e));
         a->mapped_slices = i + 1;
+        a->ever_mapped = true;
         e = hipMemSetAccess(a->base + i * a->slice, a->slice, &acc, 1);
         if (e != hipSuccess) return sq::fail(SQ_ERR_HIP, "sq_arena: hipMemSetAccess of slice %zu failed: %s", i, hipGetErrorString(e));
     }
@@ -303,6 +320,7 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
                 break;
             }
             a->mapped_slices = i + 1;
+            a->ever_mapped = true;
             if (hipMemSetAccess(a->base + i * slice, slice, &acc, 1) != hipSuccess) bad = true;
         }
         t_map += now_s() - tc;
@@ -317,8 +335,9 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     auto unmap_candidates = [&]() {
         (void)hipStreamSynchronize(st);
         unmap_all(a);
-        (void)hipMemAddressFree(a->base, cand_bytes);
+        retire_range(a->base, cand_bytes, a->ever_mapped);
         a->base = nullptr;
+        a->ever_mapped = false;
     };
     if (bad || hipGetLastError() != hipSuccess || ncand < n) {
         sq::fail(SQ_ERR_HIP, "sq_arena_create: mapping or probing the candidate slices failed");
@@ -347,14 +366,14 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     I.max_pair_gbs = (float)ghi;
     for (int c = 0; c < SQ_ARENA_MAX_CLASSES; ++c) I.class_slices[c] = I.class_candidates[c] = 0;
     for (size_t s = 0; s < ncand; ++s) I.class_candidates[class_of_slice(s)]++;
-    // The candidates are unmapped here, but their RANGE stays reserved until the arena's own range has been reserved: the arena
-    // must not come back at an address the candidates were mapped at.  (Seen with the plain-C caller of the test suite under
-    // ROCm 7.2's runtime: the arena was given the candidates' address, kernels and small copies saw the new mapping, a 120-KB
-    // hipMemcpy to the host still read the slice that USED to be there.)
+    // The candidates are unmapped here; their RANGE is retired (retire_range), so the arena -- reserved below -- cannot come back
+    // at an address the candidates were mapped at.
     (void)hipStreamSynchronize(st);
     unmap_all(a);
     char *cand_base = a->base;
+    const bool cand_mapped = a->ever_mapped;
     a->base = nullptr;
+    a->ever_mapped = false;
     if (trace_on()) fprintf(stderr, "[sq_arena] unmap of the candidates: %.1f ms\n", (now_s() - tp) * 1e3);
     tp = now_s();
     std::vector<int> chosen;
@@ -393,7 +412,7 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     tp = now_s();
     a->bytes = n * slice;
     e = hipMemAddressReserve((void **)&a->base, a->bytes, 0, nullptr, 0);
-    (void)hipMemAddressFree(cand_base, cand_bytes);
+    retire_range(cand_base, cand_bytes, cand_mapped);
     if (e != hipSuccess) {
         a->base = nullptr;
         sq::fail(SQ_ERR_HIP, "sq_arena_create: hipMemAddressReserve of %zu bytes failed: %s", a->bytes, hipGetErrorString(e));

@@ -395,16 +395,17 @@ class PlaneStreamWriter:
             item = self._queue.get()
             if item is None:
                 return
-            slot, coords, event = item
+            slot, coords, event, target = item
+            path, row_offset, level_heights = target
             try:
                 event.synchronize()
                 if self._blosc:
-                    self.bytes_written += self._write_frames(slot, coords)
+                    self.bytes_written += self._write_frames(slot, coords, path, row_offset)
                     continue
                 levels = [h.numpy() for h in self._host[slot]]
-                self.bytes_written += write_plane_levels(self.path, levels, coords, self.chunks, self.compression,
-                                                         self.level, pool=self._pool, row_offset=self.row_offset,
-                                                         level_heights=self.level_heights)
+                self.bytes_written += write_plane_levels(path, levels, coords, self.chunks, self.compression,
+                                                         self.level, pool=self._pool, row_offset=row_offset,
+                                                         level_heights=level_heights)
             except BaseException as exc:   # surfaced by the next acquire() / close()
                 self._error = exc
             finally:
@@ -416,7 +417,7 @@ class PlaneStreamWriter:
         full_h = level_yx[0] if self.level_heights is None else int(self.level_heights[lv])
         return min(self.chunks[3], full_h), min(self.chunks[4], level_yx[1])
 
-    def _write_frames(self, slot: int, coords: Sequence[tuple]) -> int:
+    def _write_frames(self, slot: int, coords: Sequence[tuple], path: str, row_offset: int) -> int:
         """Blosc mode: the chunk offsets of this slot are on the host; fetch exactly the packed frames (compressed bytes
         only cross PCIe) and write one file per non-empty chunk."""
         import torch
@@ -441,10 +442,10 @@ class PlaneStreamWriter:
         for lv, (enc, (frames, offsets, _)) in enumerate(zip(self._enc[slot], self._host[slot])):
             n_planes_geo, h, w, _, cy, cx = enc.geometry
             ncy, ncx = -(-h // cy), -(-w // cx)
-            y_off = self.row_offset >> lv
+            y_off = row_offset >> lv
             cyf = cy
             if y_off % cyf:
-                raise ValueError(f"row band at level-0 row {self.row_offset} does not start on a chunk row of level {lv}")
+                raise ValueError(f"row band at level-0 row {row_offset} does not start on a chunk row of level {lv}")
             off = offsets.numpy()
             per_plane = ncy * ncx
             sizes = np.diff(off[:len(coords) * per_plane + 1])
@@ -457,7 +458,7 @@ class PlaneStreamWriter:
                 i, rem = divmod(k, per_plane)
                 iy, ix = divmod(rem, ncx)
                 t, c, z = coords[i]
-                cdir = os.path.join(self.path, str(lv), str(t), str(c), str(z), str(y_off // cyf + iy))
+                cdir = os.path.join(path, str(lv), str(t), str(c), str(z), str(y_off // cyf + iy))
                 if cdir not in made:
                     os.makedirs(cdir, exist_ok=True)
                     made.add(cdir)
@@ -517,13 +518,35 @@ class PlaneStreamWriter:
                         h[p].copy_(d[p], non_blocking=True)
             event.record()
         self._free[slot].clear()
-        self._queue.put((slot, list(coords), event))
+        self._queue.put((slot, list(coords), event, (self.path, self.row_offset, self.level_heights)))
+
+    def retarget(self, path: str, row_offset: int = 0, level_heights: Optional[Sequence[int]] = None) -> None:
+        """The planes submitted FROM NOW ON belong to another store of the same geometry (the next well, the next timepoint): what
+        is still in flight keeps the target it was submitted with.  One writer then serves a whole run, and the chunks of region k
+        reach the disk while region k + 1 is read, registered and fused (``drain`` before anything reads the stores)."""
+        self.path = path
+        self.row_offset, self.level_heights = int(row_offset), (None if level_heights is None else list(level_heights))
+
+    def matches(self, shapes: Sequence[tuple], dtype, batch: int, compression: str, chunks) -> bool:
+        """Can this writer take planes of these level shapes (its buffers are sized for one geometry)?"""
+        from . import native
+        yx = [tuple(s[3:]) for s in shapes]
+        return (self._thread.is_alive() and self.batch == int(batch) and self.compression == compression and self.chunks == tuple(chunks)
+                and [tuple(t.shape[1:]) for t in self._dev[0]] == yx
+                and self._dev[0][0].dtype == native.torch_dtype_of(np.dtype(dtype).type))
+
+    def drain(self) -> None:
+        """Wait until everything submitted so far is on disk (the writer stays usable)."""
+        for e in self._free:
+            e.wait()
+        self._check()
 
     def close(self):
         for e in self._free:
             e.wait()
-        self._queue.put(None)
-        self._thread.join()
+        if self._thread.is_alive():
+            self._queue.put(None)
+            self._thread.join()
         self._pool.shutdown(wait=True)
         self._check()
 

@@ -109,6 +109,10 @@ class Stitcher:
         self.canvas_arena_min_bytes = int(os.environ.get('SQ_CANVAS_ARENA_MIN_BYTES', 2 << 30))
         self._arena = None
         self._arena_unsupported = False
+        # the stream writer of the .ome.zarr path lives across regions of one geometry (its two slots alternate: the chunks of
+        # region k are written while region k + 1 is read, registered and fused); run() drains it once at the end
+        self._stream_writer = None
+        self._defer_drain = False
         self.canvas_arena_info = None
         self.init_stitching_parameters()
 
@@ -814,8 +818,8 @@ class Stitcher:
                     done[slot].record()
         finally:
             pool.shutdown(wait=True)
-            if writer is not None:
-                writer.close()
+            if writer is not None and not self._defer_drain:
+                writer.drain()      # everything of this region is on disk when the call returns (run() defers it to its end)
         torch.cuda.synchronize(self.device)
         print(f"Time to stitch region {region} timepoint {timepoint}: {time.time() - start_time}")
         return flat_canvas, plane_ids
@@ -873,6 +877,13 @@ class Stitcher:
                 raise ValueError(f"row band {row_band} is too short for {len(level_heights)} pyramid levels")
 
         def make_writer(batch):
+            chunks = self.chunks or (1, 1, 1, 512, 512)
+            w = self._stream_writer
+            if w is not None and w.matches(shapes, self.dtype, batch, self.zarr_compression, chunks):
+                w.retarget(output_path, row_offset, level_heights)      # the same geometry: the next store through the same writer
+                made.append(w)
+                return w
+            self._close_stream_writer()
             key = ('writer', tuple(tuple(s[3:]) for s in shapes), batch, np.dtype(self.dtype).str)
             cached = self._buffer_cache.get(key)
             arena = None
@@ -887,11 +898,33 @@ class Stitcher:
                                                   buffers=cached, row_offset=row_offset,
                                                   level_heights=level_heights, canvas_arena=arena))
             self._keep_buffers(key, made[-1].buffers)
+            self._stream_writer = made[-1]
             return made[-1]
 
+        before = self._stream_writer.bytes_written if self._stream_writer is not None else 0
         _, ids = self.stitch_planes(timepoint, region, only_planes, progress_callback, stream_to=make_writer, row_band=row_band)
-        self.last_bytes_written = sum(w.bytes_written for w in made)
+        # bytes of this region's chunks (under run() the writer is drained at the end: the count then lags by what is in flight)
+        self.last_bytes_written = sum(w.bytes_written for w in set(made)) - (before if self._stream_writer in made else 0)
         return output_path
+
+    def close(self) -> None:
+        """Give back what the instance holds beyond its Python objects: the stream writer's threads, the canvas arena."""
+        self._close_stream_writer()
+        if self._arena is not None and not self._arena.in_use():
+            self._arena.close()
+        self._arena = None
+
+    def __del__(self):
+        try:
+            self._close_stream_writer()
+        except Exception:
+            pass
+
+    def _close_stream_writer(self) -> None:
+        """Everything submitted is on disk and the writer's threads are gone (end of run(), a change of geometry, an error)."""
+        w, self._stream_writer = getattr(self, '_stream_writer', None), None
+        if w is not None:
+            w.close()
 
     def _run_region_by_planes(self, timepoint, region, rank, world):
         """One region shared by all ranks.  With at least as many (channel, z) planes as ranks, every
@@ -1025,6 +1058,25 @@ class Stitcher:
         units = [(int(t), region) for t in self.timepoints for region in self.regions]
         n_units = len(units)
         output_path = None
+        try:
+            self._defer_drain = True      # regions of one geometry stream through ONE writer; it is drained once, below
+            output_path = self._run_units(units, n_units, rank, world, coll, pair_sharded)
+        finally:
+            self._defer_drain = False
+            self._close_stream_writer()
+        sharding.barrier()
+        self.starting_saving.emit(True)
+        if self.merge_timepoints or self.merge_hcs_regions:
+            print("Note: merging timepoints / HCS regions is an output-format step outside the hot-path scope; "
+                  "per-(timepoint, region) stores were written.")
+        final_path = os.path.join(self.output_folder, f"{self.timepoints[-1]}_stitched",
+                                  f"{self.regions[-1]}_stitched{self.output_format}")
+        self.finished_saving.emit(final_path, self.dtype)
+        print(f"Total processing time: {time.time() - stime}")
+
+    def _run_units(self, units, n_units, rank, world, coll, pair_sharded):
+        """The (timepoint, region) loop of run(): returns the last output path."""
+        output_path = None
         shared = world > 1 and n_units < world and self.output_format.endswith('.zarr')
         my_rows = {}      # unit index -> shift row measured by this rank (per-region registration)
         if shared:
@@ -1068,12 +1120,4 @@ class Stitcher:
             print(f"Completed region {region} (saved to {output_path}): {time.time() - rtime}")
         if self.use_registration:
             self._write_shift_table(n_units, my_rows, rank, world, coll, shared)
-        sharding.barrier()
-        self.starting_saving.emit(True)
-        if self.merge_timepoints or self.merge_hcs_regions:
-            print("Note: merging timepoints / HCS regions is an output-format step outside the hot-path scope; "
-                  "per-(timepoint, region) stores were written.")
-        final_path = os.path.join(self.output_folder, f"{self.timepoints[-1]}_stitched",
-                                  f"{self.regions[-1]}_stitched{self.output_format}")
-        self.finished_saving.emit(final_path, self.dtype)
-        print(f"Total processing time: {time.time() - stime}")
+        return output_path

@@ -205,3 +205,26 @@ def test_streamed_run_fuses_into_arena_canvases(tmp_path, monkeypatch):
     st3.calculate_shifts(st3.timepoints[0], st3.regions[0])
     np.testing.assert_array_equal(st3.stitch_region(int(t), region), arrays[f'{key}_canvas'])
     assert st3._arena_unsupported and st3._arena is None
+
+
+def test_an_address_that_was_mapped_is_never_mapped_again():
+    """Arenas created and destroyed one after the other: no arena comes back inside an address range an earlier one (or its
+    candidates) had mapped -- such ranges are retired, not freed -- and a large device-to-host copy of what a kernel has just
+    written into the new arena reads exactly that (with freed-and-reused ranges the copy engines read the slices that USED to be
+    mapped there: a freshly fused canvas came back as an earlier arena's zeros)."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    seen = []
+    for k in range(6):
+        arena = native.DeviceArena(48 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=16 * MiB, candidate_bytes=96 * MiB)
+        lo, hi = arena.base, arena.base + arena.nbytes
+        for a, b in seen:
+            assert hi <= a or lo >= b, f'arena {k} at [{lo:#x}, {hi:#x}) overlaps the retired range [{a:#x}, {b:#x})'
+        seen.append((lo, hi))
+        t = arena.take(40 * MiB).view(torch.int32)
+        t.fill_(0x01010101 * (k + 1))                      # a kernel writes through the page tables
+        torch.cuda.synchronize()
+        host = t.cpu().numpy()                              # the runtime's copy of 40 MiB, across slice boundaries
+        assert (host == 0x01010101 * (k + 1)).all(), f'arena {k}: the copy read something else than the kernel wrote'
+        del t
+        arena.close()
