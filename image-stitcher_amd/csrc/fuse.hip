@@ -189,15 +189,18 @@ __device__ __forceinline__ uint32_t cvt_u32_sat(float f) {
 
 // RND = 1 (feather mode rounds the float32 quotient half to even): the reference's result then hangs
 // on how n/g rounds to float32 right next to a representable k + 0.5, and n/g can be within 2^-48 of
-// that float midpoint -- the short sequence is not enough there (the exhaustive test finds two gain
-// mantissas per binade that fail, e.g. 4075 / 0x1.dbf3fep-3).  This is the full IEEE sequence
-// (Newton step on the reciprocal, quotient, two exact-residual corrections) minus its v_div_scale /
-// v_div_fmas / v_div_fixup range handling, which this operand class never needs: 8 slots, not 11.
+// that float midpoint -- with the RAW hardware reciprocal the short sequence is not enough there (401 of
+// the 2^39 operand pairs of a binade come out one ulp off, e.g. 4075 / 0x1.dbf3fep-3).  With ONE Newton
+// step on the reciprocal it is: on gfx950 v_rcp_f32 + one step IS the correctly rounded reciprocal for
+// every one of the 2^23 mantissas, and Markstein's theorem then makes quotient + one exact-residual
+// correction the correctly rounded quotient (tools/div_probe.hip: 0 of 2^39 pairs differ in every binade
+// tried, either sign; the second correction of rounds 1-3 -- the compiler's own IEEE sequence has it --
+// changed nothing).  6 slots, not the compiler's 11; sq_selftest_flat_divide compares it with the
+// compiler's division for every operand pair, on the GPU the tests run on.
 __device__ __forceinline__ float div_u16_normal_ieee(float n, float g) {
     float r = __builtin_amdgcn_rcpf(g);
     r = fmaf(fmaf(-g, r, 1.0f), r, r);
-    float q = n * r;
-    q = fmaf(fmaf(-g, q, n), r, q);
+    const float q = n * r;
     return fmaf(fmaf(-g, q, n), r, q);
 }
 template <int RND>
@@ -778,8 +781,8 @@ __device__ __forceinline__ float recip_for(float g) {
 template <int RND>
 __device__ __forceinline__ float quot_one(float n, float g, float r) {
     float q = n * r;
-    q = fmaf(fmaf(-g, q, n), r, q);
-    if (RND) q = __builtin_rintf(fmaf(fmaf(-g, q, n), r, q));
+    q = fmaf(fmaf(-g, q, n), r, q);      // r refined (RND = 1): the correctly rounded quotient (div_u16_normal_ieee)
+    if (RND) q = __builtin_rintf(q);
     return q;
 }
 // float64 gains (overwrite mode): the arithmetic of div_u16_normal_f64 with its reciprocal -- v_rcp_f64 and two Newton
@@ -808,8 +811,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // div_u16_normal_ieee / div_by_refined on two lanes: n / d correctly rounded, r = the refined reciprocal of d
 __device__ __forceinline__ f32x2 div_by_refined2(f32x2 n, f32x2 d, f32x2 r) {
-    f32x2 q = n * r;
-    q = pk_fma(pk_fma(-d, q, n), r, q);
+    const f32x2 q = n * r;
     return pk_fma(pk_fma(-d, q, n), r, q);
 }
 #ifndef SQ_FEATHER_PACKED
@@ -1434,20 +1436,20 @@ void fuse_feather_kernel(const FuseParams P, const int64_t n_items, const int64_
 // The z planes of a channel share the gain image AND the geometry, so everything of a blended voxel that does not
 // depend on the pixel values is the same for them: the two gains and their refined reciprocals, the two weights, their
 // sum and ITS refined reciprocal.  A thread works that out once per 8-pixel group and then runs the planes' pixels
-// through it: per plane and voxel two quotients of 5 instructions (div_u16_normal_ieee with the reciprocal handed in),
-// two products, one sum, the division by the weight sum in the same 5-instruction form, round, clip, pack -- about 27
-// VALU instructions against 45 for a plane on its own.  The arithmetic is the per-plane blend's, operation for
-// operation: v_k = n_k / g_k correctly rounded, acc = w_0 v_0 + w_1 v_1 (multiply and add separate), acc / wsum
-// correctly rounded.  The last one is the IEEE sequence (Newton step on the reciprocal, quotient, two exact-residual
-// corrections) without its v_div_scale / v_div_fmas / v_div_fixup range handling, which cannot trigger here: wsum is an
-// integer in [2, 2^14], and with every gain of the plane moderate (2^-20 <= |g| < 2^20: bit 1 of the gain class, else
-// the plane is a group of one) acc is 0 or 2^-44 <= |acc| < 2^53.  sq_selftest_blend_divide compares it with the
-// compiler's division on the device.
+// through it: per plane and voxel two quotients of 3 instructions (div_u16_normal_ieee with the reciprocal handed in),
+// two products, one sum, the division by the weight sum in the same 3-instruction form, round, clip, pack -- about 20
+// VALU instructions (half as many on the packed-float32 pipe) against 45 for a plane on its own.  The arithmetic is the
+// per-plane blend's, operation for operation: v_k = n_k / g_k correctly rounded, acc = w_0 v_0 + w_1 v_1 (multiply and add
+// separate), acc / wsum correctly rounded.  Each quotient is Markstein's: refined reciprocal (one Newton step: the correctly
+// rounded reciprocal on this hardware), n r, one exact-residual correction -- without the compiler's v_div_scale /
+// v_div_fmas / v_div_fixup range handling, which cannot trigger here: wsum is an integer in [2, 2^14], and with every gain
+// of the plane moderate (2^-20 <= |g| < 2^20: bit 1 of the gain class, else the plane is a group of one) acc is 0 or
+// 2^-44 <= |acc| < 2^53.  sq_selftest_blend_divide compares acc / wsum with the compiler's division on the device for every
+// mantissa of acc x every weight sum (rounds 1-3 ran a second correction; tools/div_probe.hip: it never changed a bit).
 // Items of one tile go through process_item_zg<.., RND = 1>; spans that three or four tiles cover (the corners of a
 // grid, (overlap / tile)^2 of the canvas) take the per-plane blend, plane after plane.
 __device__ __forceinline__ float div_by_refined(float n, float d, float r) {   // r = recip_for<1>(d)
-    float q = n * r;
-    q = fmaf(fmaf(-d, q, n), r, q);
+    const float q = n * r;
     return fmaf(fmaf(-d, q, n), r, q);
 }
 
@@ -1456,8 +1458,8 @@ __device__ __forceinline__ float div_by_refined(float n, float d, float r) {   /
 // gain) / none (zero) -- the uint16 canvas sends those through process_item_zg's pipelined rows, which write the tile dtype.
 // A float32 canvas is held to the north star's tolerance for fused float voxels, 1e-5 relative, not to the bits of the
 // definition: its quotients are n * r and acc * r with r the reciprocal after one Newton step (each within 2^-22 of the
-// correctly rounded quotient) instead of the five-instruction exact sequence -- 3 instructions per blended voxel instead of
-// 15.  Integer canvases stay bit-equal to the definition (rounding half to even hangs on the exact quotient).
+// correctly rounded quotient) instead of the three-instruction exact sequence -- 3 instructions per blended voxel instead of
+// 9.  Integer canvases stay bit-equal to the definition (rounding half to even hangs on the exact quotient).
 template <int FLAT, bool FULL, typename OutT = uint16_t, int NREF = 2>
 __device__ __forceinline__ void blend_item_zg(const FuseParams &P, const UnitAux &A, const int gn, const Item &it, const int tid) {
     typedef uint16_t T;
