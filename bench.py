@@ -162,7 +162,11 @@ def main():
                              "or use the default workload (cfg4, strong scaling)")
         out = run_region(ctx)
         if world == 1 and args.workload is None and not args.planes and args.traffic_bytes is None and not args.no_live_traffic:
-            torch.cuda.empty_cache()          # the passes are child processes of their own: they need the HBM this one held
+            while ARENAS:                     # the passes are child processes of their own: they need the HBM this one held
+                ARENAS.pop().close()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             try:
                 live = live_traffic(n_planes=wl['channels'] * wl['nz'])
             except Exception as exc:      # whatever goes wrong around the profiler must not cost the line its other numbers
@@ -221,8 +225,10 @@ def live_traffic(n_planes, timeout_s=120):
                 return None
             files = glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True)
             if proc.returncode != 0 or not files:
+                # the program's own words, not the profiler's closing log lines
+                said = [l for l in err.decode(errors='replace').splitlines() if not l.startswith(('W2', 'I2', 'E2')) and 'amdgpu.ids' not in l]
                 print(f'[bench] live traffic: {counter} pass failed (rc {proc.returncode}); keeping the committed measurement: '
-                      f'{err.decode(errors="replace")[-300:]}', file=sys.stderr)
+                      + ' | '.join(said[-12:])[-1500:], file=sys.stderr)
                 return None
             with open(files[0]) as fh:
                 vals = [float(r['Counter_Value']) for r in csv.DictReader(fh)

@@ -768,6 +768,11 @@ struct UnitAux {
     Seam seam;              // feather: tile and source origin of a blended item's second reference (flags 0)
     Seam first;             // feather: tile and source origin of the item's first reference
 };
+// feather: + the third and fourth reference of an item at a corner of the grid (blend_item_zgn)
+struct FeatherAux : UnitAux {
+    Seam xref[2];
+    const void *xtile[2][ZB];
+};
 
 // RND = 0 (overwrite: truncate): Markstein with r = v_rcp_f32(g), the arithmetic of div_u16_normal.
 // RND = 1 (feather, a voxel one tile covers: round half to even): the arithmetic of div_u16_normal_ieee with its Newton
@@ -1777,6 +1782,156 @@ __device__ __forceinline__ void blend_item_zg4(const FuseParams &P, const UnitAu
     }
 }
 
+// Spans that THREE or FOUR tiles cover (the corners of a grid: 1.3 % of config 3's canvas, and 12 % of the launch while they went
+// through the per-plane blend plane after plane -- every plane a chain of descriptor, pointer and pixel loads of its own:
+// profiles/r04_exp_feather_by_cover.log).  The grouped form: a thread takes one 8-voxel group through all references and planes --
+// weights and gain reciprocals once per reference, no store before the last load -- with blend_item_zg's arithmetic per reference and
+// blend_group's order of summation (acc = w_0 v_0, then + w_k v_k; multiply and add separate), so an integer canvas is the
+// per-plane blend's bit for bit and a float canvas is held to 1e-5 relative like the two-tile strips.  FLAT: 0 or 1.
+template <int FLAT, bool FULL, typename OutT>
+__device__ __forceinline__ void blend_item_zgn(const FuseParams &P, const FeatherAux &A, const int gn, const Item &it, const int tid) {
+    static_assert(FLAT == 0 || FLAT == 1, "float32 gains or none");
+    typedef uint16_t T;
+    constexpr int VEC = 8, MAXR = 4;
+    constexpr bool F32OUT = sizeof(OutT) == 4;
+    const int rows = it.hw >> 16, n = it.hw & 0xFFFF;
+    const bool four = sgpr((int)it.nref) == 4;      // else three
+    OutT *cplane[ZB];
+    const T *tp[MAXR][ZB];
+#pragma unroll
+    for (int z = 0; z < ZB; ++z) {
+        const int zz = (FULL || z < gn) ? z : 0;
+        cplane[z] = static_cast<OutT *>(P.canvas) + (int64_t)sgpr(A.g.plane[zz]) * P.canvas_plane_stride;
+        tp[0][z] = sgpr(static_cast<const T *>(A.tile[zz]));
+        tp[1][z] = sgpr(static_cast<const T *>(A.ltile[zz]));
+        tp[2][z] = sgpr(static_cast<const T *>(A.xtile[0][zz]));
+        tp[3][z] = sgpr(static_cast<const T *>(A.xtile[1][zz]));
+    }
+    const float *flat = FLAT ? static_cast<const float *>(P.flat_ptrs[sgpr(A.g.plane[0])]) : nullptr;
+    const int ry[MAXR] = {sgpr(A.first.b), sgpr(A.seam.b), sgpr(A.xref[0].b), sgpr(A.xref[1].b)};
+    const int rx[MAXR] = {sgpr(A.first.c), sgpr(A.seam.c), sgpr(A.xref[0].c), sgpr(A.xref[1].c)};
+    const int G = n / VEC + 1;   // upper bound of the whole groups of a row
+    auto refined = [](f32x2 d) {
+        const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return pk_fma(pk_fma(-d, r, f32x2{1.0f, 1.0f}), r, r);
+    };
+    for (int idx = tid; idx < rows * G; idx += 256) {
+        const int r = idx / G, j = idx - r * G;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(OutT)) & (VEC - 1));
+        const int v = (mis ? 1 : 0) + j;
+        if (v >= (n + mis) / VEC) continue;
+        const int p0 = v * VEC - mis;
+        f32x2 acc[ZB][4], ws[4];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < 3 || four) {
+                const int y = ry[k] + r, x = rx[k] + p0;
+                const int64_t so = (int64_t)y * P.tile_pitch + x;
+                f32x2 g[4], rr[4], w[4];
+                if constexpr (FLAT != 0) {
+                    const float *gp = flat + (int64_t)y * P.tile_w + x;
+                    const f32x4 a = ldg<F32x4U>(gp), b = ldg<F32x4U>(gp + 4);
+                    g[0] = f32x2{a[0], a[1]}, g[1] = f32x2{a[2], a[3]}, g[2] = f32x2{b[0], b[1]}, g[3] = f32x2{b[2], b[3]};
+                }
+                u32x4 raw[ZB];
+#pragma unroll
+                for (int z = 0; z < ZB; ++z)
+                    if (FULL || z < gn) raw[z] = ldg<U32x4U>(tp[k][z] + so);
+                const int wy = min(y + 1, P.tile_h - y);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if constexpr (FLAT != 0) rr[h] = refined(g[h]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) w[h][c] = (float)min(min(x + 2 * h + c + 1, P.tile_w - (x + 2 * h + c)), wy);
+                    ws[h] = k == 0 ? w[h] : ws[h] + w[h];
+                }
+#pragma unroll
+                for (int z = 0; z < ZB; ++z)
+                    if (FULL || z < gn) {
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            f32x2 px = {(float)(raw[z][h] & 0xFFFFu), (float)(raw[z][h] >> 16)};
+                            if constexpr (FLAT != 0) px = F32OUT ? px * rr[h] : div_by_refined2(px, g[h], rr[h]);
+                            const f32x2 t = w[h] * px;      // multiply and add separate (-ffp-contract=off), like numpy
+                            acc[z][h] = k == 0 ? t : acc[z][h] + t;
+                        }
+                    }
+            }
+        f32x2 rw[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rw[h] = refined(ws[h]);
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                f32x2 o[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) o[h] = F32OUT ? acc[z][h] * rw[h] : div_by_refined2(acc[z][h], ws[h], rw[h]);
+                if constexpr (F32OUT) {
+                    u32x4 lo, hi;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        lo[2 * q] = __float_as_uint(o[q][0]), lo[2 * q + 1] = __float_as_uint(o[q][1]);
+                        hi[2 * q] = __float_as_uint(o[2 + q][0]), hi[2 * q + 1] = __float_as_uint(o[2 + q][1]);
+                    }
+                    stg_nt(cplane[z] + doff + p0, lo);
+                    stg_nt(cplane[z] + doff + p0 + 4, hi);
+                } else {
+                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                    u32x4 out;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u16x2 pk = __builtin_amdgcn_cvt_pk_u16(cvt_u32_sat(__builtin_rintf(o[q][0])), cvt_u32_sat(__builtin_rintf(o[q][1])));
+                        out[q] = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
+                    }
+                    stg_nt(cplane[z] + doff + p0, out);
+                }
+            }
+    }
+    // the voxels before / after the 16-byte-aligned body of each row, one per thread and plane
+    for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
+        const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
+        const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(OutT)) & (VEC - 1));
+        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int p = -1;
+        if (l < VEC) {
+            if (l < head_end) p = l;
+        } else if (tail_start + (l - VEC) < n) {
+            p = tail_start + (l - VEC);
+        }
+        if (p < 0) continue;
+        float acc[ZB], wsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < 3 || four) {
+                const int y = ry[k] + r, x = rx[k] + p;
+                const float gk = FLAT ? ldg_s<float>(flat + (int64_t)y * P.tile_w + x) : 1.0f;
+                const float fk = FLAT ? recip_for<1>(gk) : 1.0f;
+                const float w = (float)min(min(x + 1, P.tile_w - x), min(y + 1, P.tile_h - y));
+                wsum = k == 0 ? w : __fadd_rn(wsum, w);
+#pragma unroll
+                for (int z = 0; z < ZB; ++z)
+                    if (FULL || z < gn) {
+                        float px = (float)ldg_s<T>(tp[k][z] + (int64_t)y * P.tile_pitch + x);
+                        if (FLAT) px = F32OUT ? __fmul_rn(px, fk) : div_by_refined(px, gk, fk);
+                        const float t = __fmul_rn(w, px);
+                        acc[z] = k == 0 ? t : __fadd_rn(acc[z], t);
+                    }
+            }
+        const float rws = recip_for<1>(wsum);
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                const float o = F32OUT ? __fmul_rn(acc[z], rws) : div_by_refined(acc[z], wsum, rws);
+                if constexpr (F32OUT) stg_s<OutT>(cplane[z] + doff + p, o);
+                else stg_s<OutT>(cplane[z] + doff + p, (OutT)min(cvt_u32_sat(__builtin_rintf(o)), 65535u));
+            }
+    }
+}
+
 // waves per SIMD asked of the register allocator: with gains 3 (168 VGPRs instead of 171: 0.555 against 0.532 for 2 waves,
 // 4 waves / 128 VGPRs 0.551); without gains the allocator's own choice measured best (0.588 against 0.574 / 0.581 at 3 / 4)
 #ifndef SQ_WAVES_FEATHER_ZG
@@ -1789,12 +1944,13 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = *P.n_groups;
-    auto pre = [&](int unit, const Item &it, int64_t) -> UnitAux {
-        UnitAux A;
+    auto pre = [&](int unit, const Item &it, int64_t) -> FeatherAux {
+        FeatherAux A;
         A.g = P.groups[unit];
         A.seam = Seam{-1, 0, 0, 0};
         A.first = Seam{-1, 0, 0, 0};
-        const bool one = it.nref >= 1 && it.nref <= 2, two = it.nref == 2;
+        A.xref[0] = A.xref[1] = Seam{-1, 0, 0, 0};
+        const bool one = it.nref >= 1 && it.nref <= 4, two = it.nref >= 2 && it.nref <= 4;      // (more than four: the per-plane blend)
         Ref ra{}, rb{};
         if (one) {
             ra = P.refs[it.a];
@@ -1809,10 +1965,24 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
             A.tile[z] = (one && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], ra.tile) : nullptr;
             A.ltile[z] = (two && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], rb.tile) : nullptr;
         }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool have = it.nref >= 3 + k && it.nref <= 4;
+            Ref rk{};
+            if (have) {
+                rk = P.refs[it.a + 2 + k];
+                A.xref[k] = Seam{rk.tile, rk.src_y + it.b, rk.src_x + it.c, 0};
+            }
+#pragma unroll
+            for (int z = 0; z < ZB; ++z) A.xtile[k][z] = (have && z < A.g.n) ? tile_ptr<T>(P, A.g.plane[z], rk.tile) : nullptr;
+        }
         return A;
     };
-    auto body = [&](int, const Item &it, const UnitAux &A) {
+    auto body = [&](int, const Item &it, const FeatherAux &A) {
         const int gn = sgpr(A.g.n);
+#ifdef SQ_FEATHER_ONLY      // experiment builds (tools/build_variant.sh): only the items that 0 / 1 / 2 / 3-or-4 tiles cover
+        if ((it.nref > 3 ? 3 : it.nref) != SQ_FEATHER_ONLY) return;
+#endif
         if (gn == 1) {
             feather_one_item<T, OutT, FLAT>(P, sgpr(A.g.plane[0]), it, wave, lane);
         } else if (F32OUT && it.nref <= 1) {
@@ -1863,15 +2033,20 @@ __global__ __launch_bounds__(256, FLAT ? SQ_WAVES_FEATHER_ZG : 1) void fuse_feat
                 if (gn == ZB) blend_item_zg<FLAT, true, OutT>(P, A, gn, it, threadIdx.x);
                 else blend_item_zg<FLAT, false, OutT>(P, A, gn, it, threadIdx.x);
             }
+        } else if (FLAT != 2 && it.nref <= 4) {      // three or four tiles: a corner of the grid
+            if constexpr (FLAT != 2) {
+                if (gn == ZB) blend_item_zgn<FLAT, true, OutT>(P, A, gn, it, threadIdx.x);
+                else blend_item_zgn<FLAT, false, OutT>(P, A, gn, it, threadIdx.x);
+            }
         } else {
             for (int z = 0; z < gn; ++z) blend_item<T, OutT, FLAT, true>(P, sgpr(A.g.plane[z]), it, threadIdx.x);
         }
     };
     if (DYN) {
-        for_each_queued_item<UnitAux>(P, n_items, n_groups, pre, body);
+        for_each_queued_item<FeatherAux>(P, n_items, n_groups, pre, body);
     } else {
         __shared__ Item s_it;
-        __shared__ UnitAux s_A;
+        __shared__ FeatherAux s_A;
         const int64_t n_work = (int64_t)n_groups * n_items;
         for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
             __syncthreads();

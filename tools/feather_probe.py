@@ -28,6 +28,15 @@ ptrs = bench.tile_pointer_table(tiles, plane_of_slot, torch.tensor(order, dtype=
 print(f'{P} planes, canvas {hc}x{wc}, feather plan {plan.n_items} items, rho {rho:.4f}; lib {native.LIB_PATH}', flush=True)
 
 
+if os.environ.get('FEATHER_COVER'):      # how many canvas voxels 0 / 1 / 2 / 3+ tiles cover
+    cover = torch.zeros((hc, wc), dtype=torch.int8, device=dev)
+    for top, left, h, w, y, x in rects:
+        cover[y:y + h, x:x + w] += 1
+    cnt = torch.bincount(cover.view(-1).to(torch.int64), minlength=5).cpu().numpy()
+    print('canvas voxels by number of covering tiles:', {k: f'{c / (hc * wc):.4f}' for k, c in enumerate(cnt)}, flush=True)
+    del cover
+
+
 def run(cv, n, fl, out_bytes, name):
     fp = native.pointer_table(fl, dev) if fl else None
     ms = []
