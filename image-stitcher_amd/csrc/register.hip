@@ -66,9 +66,17 @@ __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
 //   * any other length n (large prime factors: 2084 = 4 * 521, 3122 = 2 * 7 * 223, 1031): Bluestein's chirp-z form
 //     through a SMOOTH length M >= 2n - 1 (not the next power of two: 2084 -> 4320 instead of 8192 points), which is
 //     how pocketfft treats those too.
-// The longest line is what fits the 160 KB of LDS beside a few hundred bytes of reduction scratch: 9728 points, i.e.
-// any smooth crop side up to 9728 and any crop side at all up to 4860 (a 9568 x 6380 sensor gives 4784 and 3190).
-constexpr int MAX_LINE = 9728;
+// A line of up to 9728 points fits the 160 KB of LDS beside a few hundred bytes of reduction scratch: any smooth crop side up
+// to 9728 and any crop side at all up to 4860 (a 9568 x 6380 sensor gives 4784 and 3190) are transformed there.
+// LONGER lines (round 4; the reference's pocketfft takes any length, stitcher.py:503-510, 516-523) run the SAME transforms
+// with the line in the workspace instead -- one line per workgroup in one of LONG_SLOTS scratch lines, passes separated by
+// the same barriers (a workgroup's waves share their CU's L1, so a workgroup-scope barrier publishes global stores too);
+// such a line lives in the L2 (a 2^17-point line is 2 MB).  Any crop side up to 65535 is accepted that way: not fast
+// (flat loads and stores instead of LDS), but computed instead of refused.
+constexpr int MAX_LINE = 9728;              // points of a line in LDS
+constexpr int MAX_LONG_LINE = 1 << 17;      // points of a line in the workspace
+constexpr int MAX_CROP_SIDE = 65535;        // (2 * 65535 - 1 <= 2^17: every such side has a Bluestein length)
+constexpr int LONG_SLOTS = 512;             // scratch lines = workgroups of a long-line launch
 constexpr int MAX_STAGES = 16;
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -130,20 +138,24 @@ inline double plan_cost(const AxisPlan &pl) {
 inline int bluestein_m(int n) {
     AxisPlan pl;
     if (factor_plan(n, pl)) return 0;
-    int best = -1;
-    double best_cost = 0.0;
-    const int hi = std::min(MAX_LINE, 2 * n - 1 + n / 4);
-    for (int m = 2 * n - 1; m <= hi; ++m) {
-        if (!factor_plan(m, pl)) continue;
-        const double c = plan_cost(pl);
-        if (best < 0 || c < best_cost) {
-            best = m;
-            best_cost = c;
+    // a length that fits the LDS if there is one, else one for a line in the workspace
+    for (int cap : {MAX_LINE, MAX_LONG_LINE}) {
+        int best = -1;
+        double best_cost = 0.0;
+        const int hi = std::min(cap, 2 * n - 1 + n / 4);
+        for (int m = 2 * n - 1; m <= hi; ++m) {
+            if (!factor_plan(m, pl)) continue;
+            const double c = plan_cost(pl);
+            if (best < 0 || c < best_cost) {
+                best = m;
+                best_cost = c;
+            }
         }
+        if (best >= 0) return best;
     }
-    return best;
+    return -1;
 }
-inline bool line_supported(int n) { return n >= 2 && n <= MAX_LINE && bluestein_m(n) >= 0; }
+inline bool line_supported(int n) { return n >= 2 && n <= MAX_CROP_SIDE && bluestein_m(n) >= 0; }
 inline int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
 
 // Workspace carve-up, identical on host (sizes) and device (pointers).
@@ -154,6 +166,9 @@ struct Layout {
     int n0, n1, n1h, region, up;
     int sp;          // row pitch of the half spectra in elements: n1h rounded up to whole 128-byte lines (8 complex doubles)
     int m0, m1;      // Bluestein FFT length per axis, 0 = the axis length is smooth (transformed directly)
+    int long0, long1;            // the axis' line (m or n points) does not fit the LDS: transformed in a scratch line of the workspace
+    int n_slots;                 // scratch lines (0 when no axis is long)
+    int64_t scratch, slot_bytes; // the scratch lines, LONG_SLOTS x the longer long line
     AxisPlan ax0, ax1;           // stages of the axis' transform (of length n, or of the Bluestein length m)
     int64_t per_pair_spec;
 };
@@ -196,6 +211,13 @@ Layout make_layout(int n_pairs, int n0, int n1, int up) {
     L.perm1 = off;
     off += (!L.m1 && L.ax1.nf) ? align16((int64_t)n1 * 4) : 0;
     L.per_pair_spec = (int64_t)n0 * L.sp * 16;
+    L.long0 = (L.m0 ? L.m0 : n0) > MAX_LINE;
+    L.long1 = (L.m1 ? L.m1 : n1) > MAX_LINE;
+    L.n_slots = (L.long0 || L.long1) ? LONG_SLOTS : 0;
+    L.slot_bytes = (int64_t)std::max(L.long0 ? (L.m0 ? L.m0 : n0) : 0, L.long1 ? (L.m1 ? L.m1 : n1) : 0) * 16;
+    off = (off + 127) & ~int64_t(127);
+    L.scratch = off;
+    off += L.n_slots * L.slot_bytes;
     off = (off + 127) & ~int64_t(127);      // rows of the spectra start on 128-byte lines (of a 128-byte-aligned workspace)
     L.spectra = off;
     off += 2 * L.per_pair_spec * n_pairs;
@@ -634,16 +656,18 @@ __global__ void init_tables_kernel(RegParams P) {
 
 // spectrum of the conjugate chirp, once per axis and launch: block 0 = axis 0, block 1 = axis 1.  Left in the order
 // the forward M-point transform produces (plan order), which is the order lines_fft multiplies in.
-__global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
+// LONG: a chirp too long for the LDS is transformed where it ends up, in the workspace (axis given by the launch).
+template <bool LONG>
+__global__ __launch_bounds__(LONG ? 1024 : 256) void init_chirp_kernel(RegParams P, int only_axis) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout &L = P.L;
-    const int axis = blockIdx.x;
+    const int axis = only_axis >= 0 ? only_axis : (int)blockIdx.x;
     const int n = axis ? L.n1 : L.n0, M = axis ? L.m1 : L.m0;
-    if (!M) return;
-    cplx *x = reinterpret_cast<cplx *>(smem);
+    if (!M || (bool)(axis ? L.long1 : L.long0) != LONG) return;
     const cplx *w = reinterpret_cast<const cplx *>(P.ws + (axis ? L.chirp1 : L.chirp0));
     const cplx *twm = reinterpret_cast<const cplx *>(P.ws + (axis ? L.twm1 : L.twm0));
     cplx *spec = reinterpret_cast<cplx *>(P.ws + (axis ? L.cspec1 : L.cspec0));
+    cplx *x = LONG ? spec : reinterpret_cast<cplx *>(smem);
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int j = tid; j < M; j += nt) {   // conj(w)[m] at m and at M - m, zero between n - 1 and M - n + 1
         cplx v = {0.0, 0.0};
@@ -653,7 +677,8 @@ __global__ __launch_bounds__(256) void init_chirp_kernel(RegParams P) {
     }
     __syncthreads();
     lines_fft_plan<false, false, true>(x, 1, twm, axis ? L.ax1 : L.ax0, tid, nt);
-    for (int j = tid; j < M; j += nt) spec[j] = x[j];
+    if (!LONG)
+        for (int j = tid; j < M; j += nt) spec[j] = x[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,15 +785,13 @@ struct __attribute__((packed)) PixVec16 {   // 16 bytes of pixels at any alignme
 // One block = P.rl consecutive rows of one pair (as many as fit 64 KB of LDS, at most 8), sent through
 // the line FFT together: one barrier per pass for the batch, and eight times fewer, fuller blocks
 // than one row per block.
+// x: the block's lines, [rl][ld] -- LDS, or one scratch line of the workspace (a long axis 1)
 template <typename T, bool GEN>
-__global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void rows_forward_block(const RegParams &P, cplx *x, const int pair, const int r0, const int rl) {
     const Layout &L = P.L;
-    const int n1 = L.n1, n1h = L.n1h, sp = L.sp, rl = P.rl_fwd;
+    const int n1 = L.n1, n1h = L.n1h, sp = L.sp;
     const Axis X = axis_of(P, 1);
     const int ld = X.ld;                           // line pitch: the Bluestein length when n1 needs one
-    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
-    const int pair = blockIdx.y, r0 = blockIdx.x * rl;
     const int nrow = min(rl, L.n0 - r0);
     const sq_pair pr = P.pairs[pair];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -830,6 +853,24 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
         // noise would pick the peak.  (Golden case reg_blank_centre: the reference lands on index 0.)
         if (rrange == 0.0) A[at] = {0.0, 0.0};
         if (mrange == 0.0) B[at] = {0.0, 0.0};
+    }
+}
+// the block's scratch line of the workspace (long lines)
+__device__ __forceinline__ cplx *scratch_line(const RegParams &P) {
+    return reinterpret_cast<cplx *>(P.ws + P.L.scratch + (int64_t)blockIdx.x * P.L.slot_bytes);
+}
+template <typename T, bool GEN, bool LONG = false>
+__global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (!LONG) {
+        rows_forward_block<T, GEN>(P, reinterpret_cast<cplx *>(smem), blockIdx.y, blockIdx.x * P.rl_fwd, P.rl_fwd);
+    } else {      // a grid of scratch lines walks over (pair, row)
+        cplx *x = scratch_line(P);
+        const int64_t total = (int64_t)P.n_pairs * P.L.n0;
+        for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+            rows_forward_block<T, GEN>(P, x, (int)(w / P.L.n0), (int)(w % P.L.n0), 1);
+            __syncthreads();
+        }
     }
 }
 
@@ -948,15 +989,9 @@ __global__ __launch_bounds__(SQ_COL_THREADS) void columns_kernel(RegParams P) {
 // column spectra F and G go back to the workspace between the three transforms instead of staying in LDS -- every
 // thread re-reads exactly the elements it wrote.
 template <bool GEN>
-__global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void columns_single_block(const RegParams &P, cplx *x, double (&red)[2][1024 / 64], const int pair, const int c) {
     const Layout &L = P.L;
     const int n0 = L.n0, n1h = L.n1h, sp = L.sp;
-    cplx *x = reinterpret_cast<cplx *>(smem);   // [ld]
-    __shared__ double red[2][1024 / 64];
-    int pair, c;
-    column_block(P.share, pair, c);
-    if (c >= n1h) return;
     const int tid = threadIdx.x, nt = blockDim.x;
     cplx *A = reinterpret_cast<cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec) + c;
     cplx *B = A + (int64_t)n0 * sp;
@@ -1006,6 +1041,24 @@ __global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
     }
     lines_fft<true, true, GEN>(x, X, 1, tid, nt);
     for (int r = tid; r < n0; r += nt) A[(int64_t)r * sp] = x[r];
+}
+template <bool GEN, bool LONG = false>
+__global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[2][1024 / 64];
+    if constexpr (!LONG) {
+        int pair, c;
+        column_block(P.share, pair, c);
+        if (c >= P.L.n1h) return;
+        columns_single_block<GEN>(P, reinterpret_cast<cplx *>(smem), red, pair, c);
+    } else {      // a grid of scratch lines walks over (pair, column)
+        cplx *x = scratch_line(P);
+        const int64_t total = (int64_t)P.n_pairs * P.L.n1h;
+        for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+            columns_single_block<GEN>(P, x, red, (int)(w / P.L.n1h), (int)(w % P.L.n1h));
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1067,15 +1120,12 @@ __device__ __forceinline__ Best wave_best(Best b) {
 }
 
 template <bool GEN>
-__global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void rows_inverse_block(const RegParams &P, cplx *x, const int pair, const int rp0, const int rl) {
     const Layout &L = P.L;
-    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, sp = L.sp, rl = P.rl_inv;
+    const int n0 = L.n0, n1 = L.n1, n1h = L.n1h, sp = L.sp;
     const int nrp = (n0 + 1) / 2;
     const Axis X = axis_of(P, 1);
     const int ld = X.ld;
-    cplx *x = reinterpret_cast<cplx *>(smem);      // [rl][ld]
-    const int pair = blockIdx.y, rp0 = blockIdx.x * rl;
     const int nline = min(rl, nrp - rp0);
     const int tid = threadIdx.x, nt = blockDim.x;
     const cplx *Q = reinterpret_cast<const cplx *>(P.ws + L.spectra + (int64_t)pair * 2 * L.per_pair_spec);
@@ -1117,6 +1167,21 @@ __global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
         }
     }
 }
+template <bool GEN, bool LONG = false>
+__global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (!LONG) {
+        rows_inverse_block<GEN>(P, reinterpret_cast<cplx *>(smem), blockIdx.y, blockIdx.x * P.rl_inv, P.rl_inv);
+    } else {      // a grid of scratch lines walks over (pair, row pair)
+        cplx *x = scratch_line(P);
+        const int nrp = (P.L.n0 + 1) / 2;
+        const int64_t total = (int64_t)P.n_pairs * nrp;
+        for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+            rows_inverse_block<GEN>(P, x, (int)(w / nrp), (int)(w % nrp), 1);
+            __syncthreads();
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // K4a: whole-pixel peak
@@ -1131,7 +1196,9 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
     // coalesced read by the block
     __shared__ double amp_l[2 * (MAX_LINE / 2 + 1)];
     const double *amps = reinterpret_cast<const double *>(P.ws + L.amps) + (int64_t)pair * L.n1h * 2;
-    for (int i = tid; i < 2 * L.n1h; i += nt) amp_l[i] = amps[i];
+    const bool staged = L.n1h <= MAX_LINE / 2 + 1;      // (a long axis 1: summed straight from the workspace)
+    if (staged)
+        for (int i = tid; i < 2 * L.n1h; i += nt) amp_l[i] = amps[i];
     Best best = {-1.0, (long long)1 << 62, 0};
     for (int i = tid; i < nrp; i += nt) best = better(best, make_best(rm[2 * i], reinterpret_cast<const long long *>(rm)[2 * i + 1]));
     best = block_best(best, tid, nt);   // contains the barriers that publish amp_l
@@ -1156,8 +1223,8 @@ __global__ __launch_bounds__(256) void peak_kernel(RegParams P) {
         for (int k = 0; k < L.n1h; ++k) {
             // a column and its Hermitian mirror carry the same energy
             const double wgt = (k == 0 || (2 * k == L.n1)) ? 1.0 : 2.0;
-            sa += wgt * amp_l[2 * k];
-            sb += wgt * amp_l[2 * k + 1];
+            sa += wgt * (staged ? amp_l[2 * k] : amps[2 * k]);
+            sb += wgt * (staged ? amp_l[2 * k + 1] : amps[2 * k + 1]);
         }
         if (L.up == 1) {   // skimage :224-228 divides by size in this branch only
             sa /= (double)L.n0 * (double)L.n1;
@@ -1394,9 +1461,7 @@ __global__ __launch_bounds__(256) void selftest_normalise_kernel(unsigned long l
 int check_line(int n, const char *axis) {
     if (n < 2) return fail(SQ_ERR_INVALID, "sq_register_pairs: crop %s length %d < 2", axis, n);
     if (!line_supported(n))
-        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported: one line has to fit the 160 KB of LDS -- "
-                    "any length up to %d whose prime factors are all <= 13, any other length up to %d (its Bluestein line of "
-                    ">= 2n - 1 points)", axis, n, MAX_LINE, (MAX_LINE + 1) / 2);
+        return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: crop %s length %d not supported: at most %d pixels a side", axis, n, MAX_CROP_SIDE);
     return SQ_OK;
 }
 
@@ -1497,7 +1562,6 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     int rc;
     if ((rc = check_line(a->n0, "axis-0")) != SQ_OK) return rc;
     if ((rc = check_line(a->n1, "axis-1")) != SQ_OK) return rc;
-    if (a->n0 > 65535) return fail(SQ_ERR_UNSUPPORTED, "sq_register_pairs: n0 too large");
     const Layout L = make_layout(a->n_pairs, a->n0, a->n1, a->upsample_factor);
     if (a->workspace_bytes < L.total)
         return fail(SQ_ERR_WORKSPACE, "sq_register_pairs: workspace %lld < %lld bytes", (long long)a->workspace_bytes, (long long)L.total);
@@ -1527,7 +1591,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     // with 128 KiB / 512 threads (profiles/r03_exp_registration_shapes.log).  A power of two, so that 8 / tc blocks
     // share the spectra's 128-byte lines (P.share).
     int tc = 0;
-    if (!L.m0 && 2 * (int64_t)L.n0 * 16 <= 144 * 1024) {
+    if (!L.m0 && !L.long0 && 2 * (int64_t)L.n0 * 16 <= 144 * 1024) {
         tc = 1;
         while (tc < 8 && 2 * (int64_t)(2 * tc) * L.n0 * 16 <= 16 * 1024) tc *= 2;
         // ... but enough lines that a stage has a butterfly for every thread: n0 / r of them per line, r the largest radix
@@ -1544,11 +1608,14 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
 
     hipLaunchKernelGGL(init_tables_kernel, dim3(64), dim3(256), 0, s, P);
-    if (L.m0 || L.m1) {   // spectra of the Bluestein chirps, one block per axis
-        const size_t lds_chirp = (size_t)std::max(L.m0, L.m1) * 16;
-        if ((rc = allow_lds(init_chirp_kernel, lds_chirp)) != SQ_OK) return rc;
-        hipLaunchKernelGGL(init_chirp_kernel, dim3(2), dim3(256), lds_chirp, s, P);
+    if ((L.m0 && !L.long0) || (L.m1 && !L.long1)) {   // spectra of the Bluestein chirps, one block per axis
+        const size_t lds_chirp = (size_t)std::max(L.long0 ? 0 : L.m0, L.long1 ? 0 : L.m1) * 16;
+        if ((rc = allow_lds(init_chirp_kernel<false>, lds_chirp)) != SQ_OK) return rc;
+        hipLaunchKernelGGL(init_chirp_kernel<false>, dim3(2), dim3(256), lds_chirp, s, P, -1);
     }
+    for (int axis = 0; axis < 2; ++axis)      // ... of a long axis: in place in the workspace
+        if ((axis ? L.m1 : L.m0) && (axis ? L.long1 : L.long0))
+            hipLaunchKernelGGL(init_chirp_kernel<true>, dim3(1), dim3(1024), 0, s, P, axis);
     // Lines per block of the row kernels, measured on 240-pair batches: the forward kernel (global loads
     // + a float64 normalisation per pixel) likes many small blocks -- 16 KB of lines; the inverse kernel
     // (LDS FFT + a per-wave argmax) likes up to 8 lines within 64 KB.  Never more than keeps ~2 blocks
@@ -1556,6 +1623,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     const int64_t line_bytes = (int64_t)(L.m1 ? L.m1 : L.n1) * 16;   // a Bluestein line is m1 points long
     const int64_t dft_scratch = 0;
     auto lines_per_block = [&](int cap, int n_lines) {
+        if (L.long1) return 1;
         int rl = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (64 * 1024 - dft_scratch) / line_bytes));
         while (rl > 1 && (int64_t)a->n_pairs * ((n_lines + rl - 1) / rl) < 512) rl >>= 1;
         return rl;
@@ -1582,7 +1650,7 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     if (const char *e = getenv("SQ_REG_FWD_THREADS")) ntf = std::max(64, std::min(1024, atoi(e)));
     if (const char *e = getenv("SQ_REG_INV_THREADS")) nti = std::max(64, std::min(1024, atoi(e)));
 #endif
-    const size_t lds_fwd = (size_t)(rlf * line_bytes + dft_scratch), lds_inv = (size_t)(rli * line_bytes + dft_scratch);
+    const size_t lds_fwd = L.long1 ? 0 : (size_t)(rlf * line_bytes + dft_scratch), lds_inv = L.long1 ? 0 : (size_t)(rli * line_bytes + dft_scratch);
     // the general (mixed-radix) instantiations only where an axis' plan has mixed-radix stages: see lines_fft_plan
     const bool gen0 = L.ax0.nf > 0, gen1 = L.ax1.nf > 0;
 #define SQ_LAUNCH(KERNEL, GRID, THREADS, LDS)                                        \
@@ -1591,14 +1659,29 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), LDS, s, P);                  \
     } while (0)
     const dim3 grid_fwd((L.n0 + rlf - 1) / rlf, a->n_pairs);
-    if (a->tile_dtype == SQ_U16) {
+    // a long axis: LONG_SLOTS workgroups (fewer when there are fewer lines), each with its scratch line, walk over the lines
+    auto grid_long = [&](int64_t lines) { return dim3((unsigned)std::min<int64_t>(L.n_slots, lines)); };
+    if (L.long1) {
+        const dim3 g = grid_long((int64_t)a->n_pairs * L.n0);
+        if (a->tile_dtype == SQ_U16) {
+            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true, true>), g, 1024, 0);
+            else SQ_LAUNCH((rows_forward_kernel<uint16_t, false, true>), g, 1024, 0);
+        } else {
+            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint8_t, true, true>), g, 1024, 0);
+            else SQ_LAUNCH((rows_forward_kernel<uint8_t, false, true>), g, 1024, 0);
+        }
+    } else if (a->tile_dtype == SQ_U16) {
         if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true>), grid_fwd, ntf, lds_fwd);
         else SQ_LAUNCH((rows_forward_kernel<uint16_t, false>), grid_fwd, ntf, lds_fwd);
     } else {
         if (gen1) SQ_LAUNCH((rows_forward_kernel<uint8_t, true>), grid_fwd, ntf, lds_fwd);
         else SQ_LAUNCH((rows_forward_kernel<uint8_t, false>), grid_fwd, ntf, lds_fwd);
     }
-    if (tc < 1) {
+    if (L.long0) {
+        const dim3 g = grid_long((int64_t)a->n_pairs * L.n1h);
+        if (gen0) SQ_LAUNCH((columns_single_kernel<true, true>), g, 1024, 0);
+        else SQ_LAUNCH((columns_single_kernel<false, true>), g, 1024, 0);
+    } else if (tc < 1) {
         const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
         P.share = 8;
         const dim3 grid_col((L.n1h + 7) / 8 * 8, a->n_pairs);
@@ -1614,7 +1697,11 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
         else SQ_LAUNCH(columns_kernel<false>, grid_col, col_threads, lds_col);
     }
     const dim3 grid_inv(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs);
-    if (gen1) SQ_LAUNCH(rows_inverse_kernel<true>, grid_inv, nti, lds_inv);
+    if (L.long1) {
+        const dim3 g = grid_long((int64_t)a->n_pairs * ((L.n0 + 1) / 2));
+        if (gen1) SQ_LAUNCH((rows_inverse_kernel<true, true>), g, 1024, 0);
+        else SQ_LAUNCH((rows_inverse_kernel<false, true>), g, 1024, 0);
+    } else if (gen1) SQ_LAUNCH(rows_inverse_kernel<true>, grid_inv, nti, lds_inv);
     else SQ_LAUNCH(rows_inverse_kernel<false>, grid_inv, nti, lds_inv);
 #undef SQ_LAUNCH
     hipLaunchKernelGGL(peak_kernel, dim3(a->n_pairs), dim3(256), 0, s, P);

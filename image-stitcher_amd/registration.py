@@ -18,14 +18,15 @@ from . import native, placement
 from .placement import Shifts
 
 def crop_length_supported(n: int) -> bool:
-    """Whether the device pipeline takes a crop side of ``n`` pixels (include/squidstitch.h: one FFT line has to fit
-    the 160 KB of LDS -- any length up to 4860, smooth lengths up to 9720)."""
+    """Whether the device pipeline takes a crop side of ``n`` pixels (include/squidstitch.h: 2 ... 65535; a line that fits
+    the 160 KB of LDS -- any length up to 4860, smooth lengths up to 9720 -- is transformed there, a longer one in the
+    workspace)."""
     return bool(native.lib().sq_register_line_supported(int(n)))
 
 
 def check_crop_lengths(height: int, width: int, max_x_overlap: int, max_y_overlap: int) -> None:
     """Raise before any work if the registration crops of a ``height x width`` tile have a side the device pipeline
-    does not take.  The reference (pocketfft) has no such limit; this one is a sensor side of ~9700 pixels."""
+    does not take.  The reference (pocketfft) has no such limit; this one is a crop side of 65535 pixels."""
     sides = []
     for make, ov in ((placement.horizontal_crop_origins, max_x_overlap), (placement.vertical_crop_origins, max_y_overlap)):
         try:
@@ -35,8 +36,7 @@ def check_crop_lengths(height: int, width: int, max_x_overlap: int, max_y_overla
     bad = sorted({int(v) for v in sides if not crop_length_supported(v)})
     if bad:
         raise ValueError(f"registration crops of a {height} x {width} tile have sides of {bad} pixels; the device pipeline takes "
-                         "any crop side up to 4860 and sides with prime factors <= 13 up to 9720 (one FFT line has to fit the "
-                         "160 KB of LDS). Stitch without -r, or supply h_shift / v_shift.")
+                         "crop sides of 2 ... 65535 pixels. Stitch without -r, or supply h_shift / v_shift.")
 
 
 NORMALIZATIONS = {'phase': native.SQ_NORM_PHASE, None: native.SQ_NORM_NONE, 'none': native.SQ_NORM_NONE}

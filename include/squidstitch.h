@@ -270,14 +270,16 @@ typedef struct sq_register_args {
     int64_t workspace_bytes;
 } sq_register_args;
 
-/* Crop lengths.  One line of a transform (complex128) has to fit the 160 KB of LDS: 9728 points.
+/* Crop lengths: 2 ... 65535 pixels a side (the reference's pocketfft takes any length, stitcher.py:503-510, 516-523).
  *   - a power of two: radix-2 FFT;
  *   - any other length whose prime factors are all <= 13 (1500, 3000, 6000 ...): mixed-radix Cooley-Tukey (radix 4 / 2 / 3 /
- *     5 / 7 / 11 / 13), directly, up to 9728 points;
- *   - any other length n <= 4860: Bluestein's chirp-z form through a smooth length M >= 2n - 1 (2084 -> 4320 points);
+ *     5 / 7 / 11 / 13), directly;
+ *   - any other length n: Bluestein's chirp-z form through a smooth length M >= 2n - 1 (2084 -> 4320 points);
  * float64 throughout -- the factorisations pocketfft (the reference's FFT, via scipy / numpy) uses for such lengths.
- * Anything else: SQ_ERR_UNSUPPORTED.  (Crops are about half a tile side long, stitcher.py:504-506 / :517-519: this
- * covers every sensor up to 9720 pixels a side -- a 9568 x 6380 one gives 4784 and 3190 -- and smooth sides up to 19440.)
+ * A line of up to 9728 points (complex128) is transformed in the 160 KB of LDS: smooth sides up to 9720, any side up to 4860
+ * (crops are about half a tile side long, stitcher.py:504-506 / :517-519: every sensor up to 9720 pixels a side -- a 9568 x 6380
+ * one gives 4784 and 3190).  A longer line runs the same transform in a scratch line of the workspace (through the L2; slower,
+ * and the workspace grows by 512 such lines).  Beyond 65535: SQ_ERR_UNSUPPORTED.
  * sq_register_line_supported: 1 when a crop side of n pixels is accepted, else 0 (no device needed). */
 int sq_register_line_supported(int32_t n);
 /* Bytes of workspace sq_register_pairs needs for (n_pairs, n0, n1). */

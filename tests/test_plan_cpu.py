@@ -250,23 +250,27 @@ def test_wide_span_column_cuts_leave_no_sliver():
 
 
 def test_register_line_lengths_supported_without_a_device():
-    """include/squidstitch.h: a crop side is taken when its line fits the LDS -- a length whose prime factors are all
-    <= 13 up to 9728 points (largest such: 9720), any other length through a smooth Bluestein line of >= 2n - 1 points
-    (so up to 4860).  The reference (pocketfft) takes any length; the binding reports the limit up front."""
+    """include/squidstitch.h: every crop side from 2 to 65535 pixels is taken -- a line that fits the LDS (a length whose
+    prime factors are all <= 13 up to 9728 points, any other length through a smooth Bluestein line of >= 2n - 1 points, so up
+    to 4860) is transformed there, a longer one in the workspace (round 4; the reference's pocketfft takes any length)."""
     from image_stitcher_amd import registration
     L = native.lib()
-    ok = [2, 3, 7, 13, 64, 80, 214, 521, 1024, 1031, 1500, 2084, 3122, 3190, 3989, 4096, 4784, 4858, 4859, 4860, 6000, 8192, 9600, 9720]
-    bad = [0, 1, -5, 4861, 4862, 4863, 5003, 9721, 9728, 9733, 10000, 16384]
+    ok = [2, 3, 7, 13, 64, 80, 214, 521, 1024, 1031, 1500, 2084, 3122, 3190, 3989, 4096, 4784, 4858, 4859, 4860, 6000, 8192, 9600, 9720,
+          4861, 4862, 4863, 5003, 9721, 9728, 9733, 10000, 16384, 19997, 32768, 50000, 65521, 65535]
+    bad = [0, 1, -5, 65536, 65537, 100000, 1 << 20]
     assert [n for n in ok if not L.sq_register_line_supported(n)] == []
     assert [n for n in bad if L.sq_register_line_supported(n)] == []
-    assert registration.crop_length_supported(6000) and not registration.crop_length_supported(4861)
-    # crops are tile/2 long (stitcher.py:504-506): a 9568 x 6380 sensor passes, a 9722-pixel side (crop 9722 - 2 * 2430 = 4862 = 2 * 11 * 13 * 17) does not
+    assert registration.crop_length_supported(6000) and registration.crop_length_supported(4861) and not registration.crop_length_supported(65536)
+    # crops are tile/2 long (stitcher.py:504-506)
     registration.check_crop_lengths(6380, 9568, 256, 256)
     registration.check_crop_lengths(12000, 12000, 300, 300)
-    with pytest.raises(ValueError, match='4862'):
-        registration.check_crop_lengths(9722, 2048, 256, 256)
+    registration.check_crop_lengths(9722, 2048, 256, 256)       # crop 4862 = 2 * 11 * 13 * 17: a line in the workspace now
+    with pytest.raises(ValueError, match='65536'):
+        registration.check_crop_lengths(131072, 2048, 256, 256)       # crop = tile side / 2
     assert L.sq_register_workspace_bytes(4, 6000, 300, 10) > 0
-    assert L.sq_register_workspace_bytes(4, 4861, 300, 10) < 0 and b'not supported' in L.sq_last_error()
+    # long lines bring LONG_SLOTS scratch lines with them: 4861 is prime, its Bluestein line has >= 9721 points
+    assert L.sq_register_workspace_bytes(4, 4861, 300, 10) > L.sq_register_workspace_bytes(4, 4860, 300, 10) + 512 * 9721 * 16 - (1 << 20)
+    assert L.sq_register_workspace_bytes(4, 65536, 300, 10) < 0 and b'not supported' in L.sq_last_error()
 
 
 def test_spans_only_plan_has_the_full_plans_sizes_without_a_device():

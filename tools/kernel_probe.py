@@ -55,8 +55,9 @@ for n, h, w in (() if only_reg else ((48, 2048, 2048), (33, 512, 512))):
 # ---- registration batches -----------------------------------------------------------------------------------------
 for (th, tw, ov, label) in ((2048, 2048, 244, 'power-of-two crops 1024 x 256'), (4168, 6244, 300, 'Bluestein crops (6244 x 4168 sensor)'),
                             (3000, 3000, 288, 'mixed-radix crops (3000 x 3000 sensor: 1500 = 2^2 3 5^3)'),
-                            (6380, 9568, 300, 'long Bluestein crops (9568 x 6380 sensor: 4784, 3190)')):
-    g = 6 if th * tw <= 30e6 else 4
+                            (6380, 9568, 300, 'long Bluestein crops (9568 x 6380 sensor: 4784, 3190)'),
+                            (14192, 10640, 300, 'lines in the workspace (a 14192 x 10640 sensor: 7096 -> a Bluestein line of 14 k points, 5320 = 2^3 5 7 19)')):
+    g = 6 if th * tw <= 30e6 else (4 if th * tw <= 70e6 else 3)
     tiles = torch.from_numpy(rng.integers(0, 65535, (g * g, th, tw)).astype(np.uint16)).to(dev)
     mm = native.tile_minmax(tiles)
     (hp, (h0, h1)), (vp, (v0, v1)) = registration.all_pairs(g, g, th, tw, ov + 12, ov + 12)
