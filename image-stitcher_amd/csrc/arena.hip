@@ -33,6 +33,8 @@
 #include <ctime>
 #include <map>
 #include <utility>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -180,6 +182,8 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     const size_t chunk = std::max<size_t>(8 * spu, (n / 2 + spu - 1) / spu * spu);      // >= 4 GiB at the default sizes
     a->slice = slice;
     const double t0 = now_s();
+    size_t free_before = 0, total_mem = 0;
+    (void)hipMemGetInfo(&free_before, &total_mem);
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -410,6 +414,20 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     }
     if (trace_on()) fprintf(stderr, "[sq_arena] release of %zu slices: %.1f ms\n", ncand - n, (now_s() - tp) * 1e3);
     tp = now_s();
+    // hipMemRelease returns before the driver has the memory back (it clears what it takes back): a caller that allocates the
+    // rest of the card right after this call -- the tiles after the canvas -- met "out of memory" with 6 of 288 GiB reported free
+    // (the bench's counter pass, arena of all 4 501 candidates).  Wait until the card reports what it reported before, less the arena.
+    if (ncand > n && free_before > 0) {
+        const size_t want = free_before > n * slice + ((size_t)1 << 30) ? free_before - n * slice - ((size_t)1 << 30) : 0;
+        size_t now_free = 0;
+        for (int tries = 0; tries < 5000; ++tries) {      // at most ~10 s
+            if (hipMemGetInfo(&now_free, &total_mem) != hipSuccess || now_free >= want) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        if (trace_on()) fprintf(stderr, "[sq_arena] the released memory is back after %.1f ms (%.1f of %.1f GiB free)\n", (now_s() - tp) * 1e3,
+                                now_free / 1073741824.0, total_mem / 1073741824.0);
+        tp = now_s();
+    }
     a->bytes = n * slice;
     e = hipMemAddressReserve((void **)&a->base, a->bytes, 0, nullptr, 0);
     retire_range(cand_base, cand_bytes, cand_mapped);
@@ -447,7 +465,16 @@ extern "C" int sq_arena_destroy(sq_arena *arena) {
     const int device = arena->device;
     if (current != device) (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
+    size_t free_before = 0, total_mem = 0, now_free = 0;
+    const size_t held = arena->handles.size() * arena->slice;
+    (void)hipMemGetInfo(&free_before, &total_mem);
     release(arena);
+    // the driver has the memory back a little after hipMemRelease returns (sq_arena_create): the next allocation of the caller may
+    // need it -- wait for it, at most ~3 s
+    for (int tries = 0; held >= ((size_t)4 << 30) && tries < 1500; ++tries) {      // (small arenas: nothing anybody waits for)
+        if (hipMemGetInfo(&now_free, &total_mem) != hipSuccess || now_free + ((size_t)1 << 30) >= free_before + held) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
     if (current >= 0 && current != device) (void)hipSetDevice(current);
     return SQ_OK;
 }
