@@ -720,10 +720,17 @@ class Stitcher:
             for p in empty:
                 native.fuse_planes(zplan, torch.empty((1, 0, th, tw), dtype=flat_canvas.dtype, device=self.device),
                                    flat_canvas[slot_of[p]:slot_of[p] + 1])
-        flats_dev = {}
-        if self.apply_flatfield:
-            for ci, ff in self.flatfields.items():
-                flats_dev[ci] = torch.from_numpy(np.ascontiguousarray(ff)).to(self.device)
+        # run() streaming region after region: copies, fusion, pyramid and encoding of a region go to a stream of their own, so
+        # that the NEXT region's registration -- it reads its shifts back, i.e. waits for the stream it runs on -- does not wait for
+        # them (config 5: a (well, timepoint) unit is one batch; tools/cfg5_probe.py)
+        side = None
+        if stream_to is not None and self._defer_drain:
+            if getattr(self, '_ingest_stream', None) is None:
+                self._ingest_stream = torch.cuda.Stream(device=self.device)
+            side = self._ingest_stream
+            side.wait_stream(torch.cuda.current_stream(self.device))      # whatever the caller enqueued (flatfields, shifts) first
+        import contextlib
+        stream_ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
         # batch planes that share one rectangle list (normally: all of them)
         groups: Dict[bytes, List[int]] = {}
@@ -746,10 +753,15 @@ class Stitcher:
         processed = 0
         pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
         writer = None
-        if stream_to is not None and groups:
-            widest = max(len(rect_of[sig]) for sig in groups) * th * tw * np.dtype(self.dtype).itemsize
-            writer = stream_to(max(1, min(max(len(pl) for pl in groups.values()), budget // max(1, widest))))
+        stream_ctx.__enter__()
         try:
+            flats_dev = {}
+            if self.apply_flatfield:
+                for ci, ff in self.flatfields.items():
+                    flats_dev[ci] = torch.from_numpy(np.ascontiguousarray(ff)).to(self.device)
+            if stream_to is not None and groups:
+                widest = max(len(rect_of[sig]) for sig in groups) * th * tw * np.dtype(self.dtype).itemsize
+                writer = stream_to(max(1, min(max(len(pl) for pl in groups.values()), budget // max(1, widest))))
             for sig, plist in groups.items():
                 # ascending plane ids: the canvas slots of a chunk are then consecutive and the whole chunk
                 # goes out in ONE launch (region_data is in file-name order, i.e. z varies before channel)
@@ -762,19 +774,23 @@ class Stitcher:
                 if writer is not None:
                     batch = min(batch, writer.batch)
                 chunks = [plist[b0:b0 + batch] for b0 in range(0, len(plist), batch)]
-                n_slots = min(2, len(chunks))
+                # two slots also for a single chunk when run() streams region after region (config 5: a region is one chunk):
+                # the next region's files are then read while this region's copy and fusion are still under way
+                pipelined = writer is not None and self._defer_drain
+                n_slots = 2 if (len(chunks) > 1 or pipelined) else 1
                 key = ('ingest', batch, n, th, tw, n_slots, np.dtype(self.dtype).str)
                 bufs = self._buffer_cache.get(key)
                 if bufs is None:   # pinned staging + device mirrors, kept for the next region of the same shape
                     bufs = ([torch.empty((batch, n, th, tw), dtype=tdtype, pin_memory=True) for _ in range(n_slots)],
                             [torch.empty((batch, n, th, tw), dtype=tdtype, device=self.device) for _ in range(n_slots)],
-                            [None] * n_slots)
+                            [None] * n_slots, [0])
                     self._keep_buffers(key, bufs)
                 # the slots' "copy and fusion finished" events live with the buffers: another group (or the next
                 # region) that gets the same cached staging must wait for the H2D copy still reading it
-                staging, on_dev, done = bufs
+                staging, on_dev, done, turn = bufs
                 for k, chunk in enumerate(chunks):
-                    slot = k % n_slots
+                    slot = turn[0] % n_slots      # (the turn goes on across calls: the next region starts on the other slot)
+                    turn[0] += 1
                     if done[slot] is not None:
                         done[slot].synchronize()      # the slot's previous copy and fusion have finished
                     host = staging[slot].numpy()
@@ -817,10 +833,12 @@ class Stitcher:
                     done[slot] = torch.cuda.Event()
                     done[slot].record()
         finally:
+            stream_ctx.__exit__(None, None, None)
             pool.shutdown(wait=True)
             if writer is not None and not self._defer_drain:
                 writer.drain()      # everything of this region is on disk when the call returns (run() defers it to its end)
-        torch.cuda.synchronize(self.device)
+        if not (writer is not None and self._defer_drain):      # (run(): the writer's events order everything; it is drained at the end)
+            torch.cuda.synchronize(self.device)
         print(f"Time to stitch region {region} timepoint {timepoint}: {time.time() - start_time}")
         return flat_canvas, plane_ids
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# r04 final2: after "the released memory is back before sq_arena_create returns": arena + C-caller tests, the driver's bench command
+# r04 final2: after regions pipelined through a stream of their own in run(), and "the released memory is back before sq_arena_create returns": arena + C-caller tests, the driver's bench command
 # (with the arena trace), then the rocprofv3 kernel stats of the bench and of the feather probe on the same box
 O=gpurun_out/r4; mkdir -p $O
-timeout -k 10 600 python3 -m pytest tests/test_arena_gpu.py tests/test_c_abi_gpu.py -x -q > $O/arena_tests3.log 2>&1 || { echo arena tests failed; tail -30 $O/arena_tests3.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_arena_gpu.py tests/test_c_abi_gpu.py tests/test_stitcher_gpu.py tests/test_configs_gpu.py tests/test_distributed_gpu.py tests/test_pyramid_gpu.py -x -q > $O/arena_tests3.log 2>&1 || { echo arena tests failed; tail -30 $O/arena_tests3.log; exit 1; }
 tail -1 $O/arena_tests3.log
 SQ_ARENA_TRACE=1 timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_v40.out 2> $O/bench_v40.err || { echo bench failed; tail -30 $O/bench_v40.err; exit 1; }
 grep "^{" $O/bench_v40.out | tail -1 > $O/bench_v40.json
@@ -31,3 +31,5 @@ cp $O/feather_trace2/run_kernel_stats.csv $O/feather_v40_kernel_stats.csv
 head -6 $O/feather_v40_kernel_stats.csv | cut -c1-200
 grep "planes" $O/feather_under_rocprof2.log | tail -4
 rm -rf $O/bench_trace2 $O/feather_trace2
+timeout -k 10 300 python3 tools/cfg5_probe.py 8 2 > $O/cfg5_probe_after2.log 2>&1 || { echo cfg5 probe failed; tail -5 $O/cfg5_probe_after2.log; exit 1; }
+tail -2 $O/cfg5_probe_after2.log
