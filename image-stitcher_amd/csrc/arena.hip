@@ -14,8 +14,8 @@
 //      one reserved virtual range (hipMemAddressReserve / hipMemMap);
 //   2. classify UNITS (512 MiB of consecutively created slices: physical memory is handed out in long runs) as they come: a
 //      unit joins the first class whose reference unit it collides with -- the pair fills less than 1.17 times faster than the
-//      reference alone -- or becomes the reference of a new class; stop taking memory once the three largest classes each
-//      hold a third of the arena (or the caller's cap is reached, or the card is full);
+//      reference alone -- or becomes the reference of a new class; stop taking memory once the two largest classes each
+//      hold half of the arena or the three largest a third each (or the caller's cap is reached, or the card is full);
 //   3. choose the arena's slices round-robin over the classes, give the others back, and map the chosen ones in that order.
 // Every 200 MB of such an arena then holds all classes, wherever a plane starts and however many planes a launch writes:
 // one plane alone fills at 0.72-0.75, five consecutive planes at 0.75-0.76, the fusion kernel's structure goes from
@@ -179,7 +179,7 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     const size_t n = ((size_t)bytes + slice - 1) / slice;
     const size_t spu = unit / slice;
     const size_t cap = natural ? n : std::max(n, candidate_bytes > 0 ? (size_t)candidate_bytes / slice : n);
-    const size_t chunk = std::max<size_t>(8 * spu, (n / 2 + spu - 1) / spu * spu);      // >= 4 GiB at the default sizes
+    const size_t chunk = std::max<size_t>(8 * spu, (n / 4 + spu - 1) / spu * spu);      // >= 4 GiB at the default sizes
     a->slice = slice;
     const double t0 = now_s();
     size_t free_before = 0, total_mem = 0;
@@ -286,10 +286,15 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         class_slices_taken.assign(ref_unit.size(), 0);
         for (size_t u = 0; u < nunits; ++u) class_slices_taken[cls[u]] += spu;
     };
-    auto balanced = [&]() {
+    // enough taken: a third of the arena in each of the three largest classes, or half of it in each of the two largest -- two
+    // halves write as fast as three thirds or a five-class mix (the real kernel, one process: 0.717 against 0.710,
+    // profiles/r04_exp_arena_two_classes.log; a card that shows two classes only: 0.724 on config 3), and the driver bills
+    // every candidate slice (it clears memory it hands out and memory it takes back)
+    auto balanced = [&](size_t) {
         std::vector<size_t> c(class_slices_taken);
         std::sort(c.rbegin(), c.rend());
-        return c.size() >= 3 && c[2] >= (n + 2) / 3;
+        if (c.size() >= 3 && c[2] >= (n + 2) / 3) return true;
+        return c.size() >= 2 && c[1] >= (n + 1) / 2;
     };
     size_t have = 0;
     bool full = false;
@@ -331,7 +336,7 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         have += got;
         if (natural || bad) break;
         classify_all(have / spu);
-        if (balanced()) break;
+        if (balanced(have)) break;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -383,9 +388,19 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
     std::vector<int> chosen;
     chosen.reserve(n);
     {
+        // SQ_ARENA_TWO_CLASSES (a measurement aid): the two largest classes only, as long as they have slices
+        std::vector<char> skip(ncls, 0);
+        if ((flags & SQ_ARENA_TWO_CLASSES) && ncls > 2) {
+            std::vector<int> by_size(ncls);
+            for (int c = 0; c < ncls; ++c) by_size[c] = c;
+            std::sort(by_size.begin(), by_size.end(), [&](int x, int y) { return I.class_candidates[x] > I.class_candidates[y]; });
+            if ((size_t)I.class_candidates[by_size[0]] + (size_t)I.class_candidates[by_size[1]] >= n)
+                for (int k = 2; k < ncls; ++k) skip[by_size[k]] = 1;
+        }
         std::vector<size_t> next(ncls, 0);
         while (chosen.size() < n) {
             for (int c = 0; c < ncls && chosen.size() < n; ++c) {
+                if (skip[c]) continue;
                 size_t &p = next[c];
                 while (p < ncand && class_of_slice(p) != c) ++p;
                 if (p < ncand) {

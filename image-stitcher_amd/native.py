@@ -23,6 +23,7 @@ SQ_NORM_NONE, SQ_NORM_PHASE = 0, 1
 SQ_FUSE_FORCE_QUEUES, SQ_FUSE_FORCE_STATIC, SQ_FUSE_NO_PLANE_GROUPS, SQ_FUSE_NO_SEAM_OWNERS, SQ_FUSE_CONSECUTIVE_GROUPS = 1, 2, 4, 8, 16
 SQ_VERSION = 108
 SQ_ARENA_NATURAL_ORDER = 1
+SQ_ARENA_TWO_CLASSES = 2
 SQ_ARENA_MAX_CLASSES = 8
 
 RECT_DTYPE = np.dtype([('src_y0', '<i4'), ('src_x0', '<i4'), ('h', '<i4'), ('w', '<i4'),
@@ -437,7 +438,7 @@ class DeviceArena:
     over (the caller makes sure nothing uses the old tensors any more); ``close()`` unmaps and releases everything."""
 
     def __init__(self, nbytes: int, device=None, slice_bytes: int = 0, unit_bytes: int = 0, natural_order: bool = False, stream=None,
-                 candidate_bytes: Optional[int] = None):
+                 candidate_bytes: Optional[int] = None, two_classes: bool = False):
         import torch
         L = lib()
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
@@ -452,7 +453,7 @@ class DeviceArena:
                 free = torch.cuda.mem_get_info(self.device)[0]
                 candidate_bytes = max(int(nbytes), min(8 * int(nbytes), free - (6 << 30)))
             self._h = L.sq_arena_create(int(nbytes), int(candidate_bytes), int(slice_bytes), int(unit_bytes),
-                                        SQ_ARENA_NATURAL_ORDER if natural_order else 0, _stream_ptr(stream), C.byref(info))
+                                        (SQ_ARENA_NATURAL_ORDER if natural_order else 0) | (SQ_ARENA_TWO_CLASSES if two_classes else 0), _stream_ptr(stream), C.byref(info))
         if not self._h:
             raise NativeError(f"sq_arena_create({nbytes} bytes) failed: {L.sq_last_error().decode()}")
         self.base, self.nbytes = int(info.base_dev), int(info.bytes)

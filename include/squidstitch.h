@@ -171,12 +171,13 @@ int sq_fuse_planes(const sq_fuse_args *args, void *stream);
  *       classes each hold a third of `bytes`; the rest is given back before the call returns.  Pass what is free (less a
  *       reserve) and create the arena FIRST, while the card is still empty: typically 1.5-2.5 x bytes are taken, ~25 ms / GiB.
  *   slice_bytes: 0 = 64 MiB (a multiple of 2 MiB);  unit_bytes: 0 = 512 MiB (a multiple of the slice, >= 16 MiB)
- *   flags: SQ_ARENA_NATURAL_ORDER = skip the probe and keep the slices in creation order (the control of A/B runs)
+ *   flags: SQ_ARENA_NATURAL_ORDER = skip the probe and keep the slices in creation order (the control of A/B runs);
+ *          SQ_ARENA_TWO_CLASSES = map slices of the two largest classes only (a measurement aid: two halves against three thirds)
  * Returns NULL on failure (sq_last_error; SQ_ERR_UNSUPPORTED in the message when the platform lacks virtual memory
  * management: allocate the canvas any other way then -- every entry point takes plain device pointers).
  * ---------------------------------------------------------------------------------------- */
 #define SQ_ARENA_MAX_CLASSES 8
-typedef enum sq_arena_flags { SQ_ARENA_NATURAL_ORDER = 1 } sq_arena_flags;
+typedef enum sq_arena_flags { SQ_ARENA_NATURAL_ORDER = 1, SQ_ARENA_TWO_CLASSES = 2 } sq_arena_flags;
 typedef struct sq_arena sq_arena;
 typedef struct sq_arena_info {
     void *base_dev;       /* first byte of the arena (2 MiB aligned at least)                     */
