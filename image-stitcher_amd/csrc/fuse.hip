@@ -479,8 +479,10 @@ __device__ __forceinline__ void pipeline_rows(const Row<T> (&J)[RB], int lane) {
 #ifndef SQ_WAVES_PLAIN
 #define SQ_WAVES_PLAIN 1
 #endif
+// (round 4: 5, not 6 -- at 80 VGPRs the per-plane kernels with gains kept spill code inside their item loops, which this build
+//  does not ship any more: tools/barrier_scan.py scan_spills, tests/test_isa_cpu.py; these kernels serve groups of one)
 #ifndef SQ_WAVES_F32
-#define SQ_WAVES_F32 6
+#define SQ_WAVES_F32 5
 #endif
 #ifndef SQ_WAVES_F64
 #define SQ_WAVES_F64 1
@@ -1415,7 +1417,7 @@ __device__ __forceinline__ void feather_one_item(const FuseParams &P, int plane,
 }
 
 #ifndef SQ_WAVES_FEATHER_F32
-#define SQ_WAVES_FEATHER_F32 5
+#define SQ_WAVES_FEATHER_F32 4      // (5 until round 4: spill code inside the item loops, see SQ_WAVES_F32)
 #endif
 template <typename T, typename OutT, int FLAT, bool DYN>
 __global__ __launch_bounds__(256, (FLAT == 1 && sizeof(T) == 2 && sizeof(OutT) == 2 ? SQ_WAVES_FEATHER_F32 : 1))

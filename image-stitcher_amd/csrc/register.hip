@@ -77,6 +77,7 @@ constexpr int MAX_LINE = 9728;              // points of a line in LDS
 constexpr int MAX_LONG_LINE = 1 << 17;      // points of a line in the workspace
 constexpr int MAX_CROP_SIDE = 65535;        // (2 * 65535 - 1 <= 2^17: every such side has a Bluestein length)
 constexpr int LONG_SLOTS = 512;             // scratch lines = workgroups of a long-line launch
+constexpr int LONG_THREADS = 512;           // ... of 512 threads: 256 VGPRs each, so that the mixed-radix butterflies inside the walk over the lines do not spill
 constexpr int MAX_STAGES = 16;
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -860,7 +861,7 @@ __device__ __forceinline__ cplx *scratch_line(const RegParams &P) {
     return reinterpret_cast<cplx *>(P.ws + P.L.scratch + (int64_t)blockIdx.x * P.L.slot_bytes);
 }
 template <typename T, bool GEN, bool LONG = false>
-__global__ __launch_bounds__(1024) void rows_forward_kernel(RegParams P) {
+__global__ __launch_bounds__(LONG ? LONG_THREADS : 1024) void rows_forward_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (!LONG) {
         rows_forward_block<T, GEN>(P, reinterpret_cast<cplx *>(smem), blockIdx.y, blockIdx.x * P.rl_fwd, P.rl_fwd);
@@ -1043,7 +1044,7 @@ __device__ __forceinline__ void columns_single_block(const RegParams &P, cplx *x
     for (int r = tid; r < n0; r += nt) A[(int64_t)r * sp] = x[r];
 }
 template <bool GEN, bool LONG = false>
-__global__ __launch_bounds__(1024) void columns_single_kernel(RegParams P) {
+__global__ __launch_bounds__(LONG ? LONG_THREADS : 1024) void columns_single_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[2][1024 / 64];
     if constexpr (!LONG) {
@@ -1168,7 +1169,7 @@ __device__ __forceinline__ void rows_inverse_block(const RegParams &P, cplx *x, 
     }
 }
 template <bool GEN, bool LONG = false>
-__global__ __launch_bounds__(1024) void rows_inverse_kernel(RegParams P) {
+__global__ __launch_bounds__(LONG ? LONG_THREADS : 1024) void rows_inverse_kernel(RegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (!LONG) {
         rows_inverse_block<GEN>(P, reinterpret_cast<cplx *>(smem), blockIdx.y, blockIdx.x * P.rl_inv, P.rl_inv);
@@ -1664,11 +1665,11 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     if (L.long1) {
         const dim3 g = grid_long((int64_t)a->n_pairs * L.n0);
         if (a->tile_dtype == SQ_U16) {
-            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true, true>), g, 1024, 0);
-            else SQ_LAUNCH((rows_forward_kernel<uint16_t, false, true>), g, 1024, 0);
+            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true, true>), g, LONG_THREADS, 0);
+            else SQ_LAUNCH((rows_forward_kernel<uint16_t, false, true>), g, LONG_THREADS, 0);
         } else {
-            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint8_t, true, true>), g, 1024, 0);
-            else SQ_LAUNCH((rows_forward_kernel<uint8_t, false, true>), g, 1024, 0);
+            if (gen1) SQ_LAUNCH((rows_forward_kernel<uint8_t, true, true>), g, LONG_THREADS, 0);
+            else SQ_LAUNCH((rows_forward_kernel<uint8_t, false, true>), g, LONG_THREADS, 0);
         }
     } else if (a->tile_dtype == SQ_U16) {
         if (gen1) SQ_LAUNCH((rows_forward_kernel<uint16_t, true>), grid_fwd, ntf, lds_fwd);
@@ -1679,8 +1680,8 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     }
     if (L.long0) {
         const dim3 g = grid_long((int64_t)a->n_pairs * L.n1h);
-        if (gen0) SQ_LAUNCH((columns_single_kernel<true, true>), g, 1024, 0);
-        else SQ_LAUNCH((columns_single_kernel<false, true>), g, 1024, 0);
+        if (gen0) SQ_LAUNCH((columns_single_kernel<true, true>), g, LONG_THREADS, 0);
+        else SQ_LAUNCH((columns_single_kernel<false, true>), g, LONG_THREADS, 0);
     } else if (tc < 1) {
         const size_t lds_col = (size_t)(L.m0 ? L.m0 : L.n0) * 16;
         P.share = 8;
@@ -1699,8 +1700,8 @@ extern "C" int sq_register_pairs(const sq_register_args *a, void *stream_) {
     const dim3 grid_inv(((L.n0 + 1) / 2 + rli - 1) / rli, a->n_pairs);
     if (L.long1) {
         const dim3 g = grid_long((int64_t)a->n_pairs * ((L.n0 + 1) / 2));
-        if (gen1) SQ_LAUNCH((rows_inverse_kernel<true, true>), g, 1024, 0);
-        else SQ_LAUNCH((rows_inverse_kernel<false, true>), g, 1024, 0);
+        if (gen1) SQ_LAUNCH((rows_inverse_kernel<true, true>), g, LONG_THREADS, 0);
+        else SQ_LAUNCH((rows_inverse_kernel<false, true>), g, LONG_THREADS, 0);
     } else if (gen1) SQ_LAUNCH(rows_inverse_kernel<true>, grid_inv, nti, lds_inv);
     else SQ_LAUNCH(rows_inverse_kernel<false>, grid_inv, nti, lds_inv);
 #undef SQ_LAUNCH

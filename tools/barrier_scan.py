@@ -63,8 +63,64 @@ def scan(path):
     return n_barriers, flagged
 
 
+def scan_spills(path):
+    """-> {kernel: number of VGPR spill / reload instructions (scratch_store / scratch_load, buffer_store / buffer_load ... offen
+    marked 'Folded Spill' / 'Folded Reload') that sit INSIDE A LOOP} for every kernel of a listing.  Spill code in the straight-line
+    prologue of a kernel runs once with every lane enabled; inside the item loops it runs under the lane masks of divergent
+    regions -- round 4: the uint16 + gains feather kernel with such spills (an experiment that kept 12 more values alive) left row
+    ends of one-tile items unwritten in queue mode; its `count` of the chunk loop, a value every lane needs, was reloaded inside a
+    region only some lanes run (profiles/r04_exp_feather_edges.log).  A loop = the instructions between a label and a LATER instruction that branches back to it."""
+    kern, idx, first_back_target, labels, spills = None, 0, {}, {}, {}
+    rows = []
+    for raw in open(path).read().splitlines():
+        code = raw.split(';')[0].strip()
+        if not code or (code.startswith('.') and not code.endswith(':')):
+            continue
+        if code.endswith(':'):
+            name = code[:-1]
+            if name.startswith('_Z'):
+                kern = name
+            labels[name] = (kern, len(rows))
+            continue
+        rows.append((kern, code, ('Folded Spill' in raw) or ('Folded Reload' in raw)))
+    loops = []                                                # (target, source) of every back edge: the loop's instructions
+    for i, (k, code, _) in enumerate(rows):
+        op = code.split()[0]
+        if op == 's_branch' or op.startswith('s_cbranch'):
+            tgt = labels.get(code.split()[-1])
+            if tgt and tgt[0] == k and tgt[1] <= i:
+                loops.append((tgt[1], i))
+    depth = [0] * (len(rows) + 1)
+    for t, src in loops:
+        depth[t] += 1
+        depth[src + 1] -= 1
+    inside = 0
+    for i, (k, code, spill) in enumerate(rows):
+        inside += depth[i]
+        if spill and inside > 0:
+            spills[k] = spills.get(k, 0) + 1
+    return spills
+
+
+def scan_spills_all(files=('fuse.hip',)):
+    """-> [(file, demangled kernel, spill instructions inside loops)] over the given csrc files, compiled here for gfx950."""
+    out = tempfile.mkdtemp(prefix='sq_isa_')
+    found = []
+    for f in files:
+        for k, n in sorted(scan_spills(listing_of(f, out)).items()):
+            name = subprocess.run(['c++filt', k or '?'], capture_output=True, text=True).stdout.strip()[:120]
+            found.append((f, name, n))
+    return found
+
+
+_LISTINGS = {}      # csrc file -> its listing, compiled once per process
+
+
 def listing_of(f, out):
+    if f in _LISTINGS and os.path.exists(_LISTINGS[f]):
+        return _LISTINGS[f]
     lst = os.path.join(out, f + '.s')
+    _LISTINGS[f] = lst
     subprocess.run(['/opt/rocm/bin/hipcc', '-std=c++17', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
                     '-S', '--cuda-device-only', '-o', lst, os.path.join(ROOT, 'image-stitcher_amd', 'csrc', f)], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -94,6 +150,9 @@ def scan_all(verbose=True):
 def main():
     total, bad = scan_all()
     print(f'{total} barriers, {len(bad)} flagged')
+    spills = scan_spills_all(sorted(f for f in os.listdir(os.path.join(ROOT, 'image-stitcher_amd', 'csrc')) if f.endswith('.hip')))
+    for f, k, n in spills:
+        print(f'{f}: {k}: {n} spill / reload instructions inside loops')
     return 1 if bad else 0
 
 
