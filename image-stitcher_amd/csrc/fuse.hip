@@ -1678,38 +1678,6 @@ __device__ __forceinline__ void blend_item_zg4(const FuseParams &P, const UnitAu
         const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
         return pk_fma(pk_fma(-d, r, f32x2{1.0f, 1.0f}), r, r);
     };
-    // The voxels before / after the 16-byte-aligned body of each row, one per thread and plane (at most 16 rows: 128 of them).
-    // Their loads are issued HERE, before the body's, and they are finished after it: as a pass of its own behind the body the
-    // row ends were a second memory round trip per item (up to 4.6 % of the launch, profiles/r04_exp_feather_edges.log).  This
-    // kernel has the registers for it (146 VGPRs, no spill code); the uint16 kernel (blend_item_zg) has not -- see there.
-    int ep = -1, er = 0;
-    float ega = 1.0f, egb = 1.0f;
-    uint32_t eva[ZB], evb[ZB];
-    if (tid < rows * 2 * VEC) {
-        er = tid / (2 * VEC);
-        const int l = tid - er * 2 * VEC;
-        const int64_t doff = (int64_t)(it.dst_y + er) * P.canvas_pitch + it.dst_x;
-        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(float)) & (VEC - 1));
-        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
-        const int head_end = min(n, v_first * VEC - mis);
-        const int tail_start = max(head_end, v_end * VEC - mis);
-        if (l < VEC) {
-            if (l < head_end) ep = l;
-        } else if (tail_start + (l - VEC) < n) {
-            ep = tail_start + (l - VEC);
-        }
-        if (NREF != 0 && ep >= 0) {
-            const int y0 = ya + er, x0 = xa + ep, y1 = yb + er, x1 = xb + ep;
-            if (FLAT) ega = ldg_s<float>(flat + (int64_t)y0 * P.tile_w + x0);
-            if (FLAT && NREF == 2) egb = ldg_s<float>(flat + (int64_t)y1 * P.tile_w + x1);
-#pragma unroll
-            for (int z = 0; z < ZB; ++z)
-                if (FULL || z < gn) {
-                    eva[z] = ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0);
-                    if constexpr (NREF == 2) evb[z] = ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
-                }
-        }
-    }
     for (int idx = tid; idx < rows * G; idx += 256) {
         const int r = idx / G, j = idx - r * G;
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
@@ -1773,34 +1741,46 @@ __device__ __forceinline__ void blend_item_zg4(const FuseParams &P, const UnitAu
                 stg_nt(cplane[z] + doff + p0, out);
             }
     }
-    if (ep >= 0) {
-        const int r = er, p = ep;
+    // the voxels before / after the 16-byte-aligned body of each row, one per thread and plane
+    for (int idx = tid; idx < rows * 2 * VEC; idx += 256) {
+        const int r = idx / (2 * VEC), l = idx - r * 2 * VEC;
         const int64_t doff = (int64_t)(it.dst_y + r) * P.canvas_pitch + it.dst_x;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(cplane[0] + doff) / sizeof(float)) & (VEC - 1));
+        const int v_first = mis ? 1 : 0, v_end = (n + mis) / VEC;
+        const int head_end = min(n, v_first * VEC - mis);
+        const int tail_start = max(head_end, v_end * VEC - mis);
+        int p = -1;
+        if (l < VEC) {
+            if (l < head_end) p = l;
+        } else if (tail_start + (l - VEC) < n) {
+            p = tail_start + (l - VEC);
+        }
+        if (p < 0) continue;
         if constexpr (NREF == 0) {
 #pragma unroll
             for (int z = 0; z < ZB; ++z)
                 if (FULL || z < gn) stg_s<float>(cplane[z] + doff + p, 0.0f);
-        } else {
-            const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
-            const float fa = FLAT ? recip_for<1>(ega) : 1.0f;
-            const float fb = (FLAT && NREF == 2) ? recip_for<1>(egb) : 1.0f;
-            const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
-            const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
-            const float rws = recip_for<1>(__fadd_rn(wa, wb));
-#pragma unroll
-            for (int z = 0; z < ZB; ++z)
-                if (FULL || z < gn) {
-                    float va = (float)eva[z];
-                    if (FLAT) va = __fmul_rn(va, fa);
-                    float o = va;
-                    if constexpr (NREF == 2) {
-                        float vb = (float)evb[z];
-                        if (FLAT) vb = __fmul_rn(vb, fb);
-                        o = __fmul_rn(__fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb)), rws);
-                    }
-                    stg_s<float>(cplane[z] + doff + p, o);
-                }
+            continue;
         }
+        const int y0 = ya + r, x0 = xa + p, y1 = yb + r, x1 = xb + p;
+        const float fa = FLAT ? recip_for<1>(ldg_s<float>(flat + (int64_t)y0 * P.tile_w + x0)) : 1.0f;
+        const float fb = (FLAT && NREF == 2) ? recip_for<1>(ldg_s<float>(flat + (int64_t)y1 * P.tile_w + x1)) : 1.0f;
+        const float wa = (float)min(min(x0 + 1, P.tile_w - x0), min(y0 + 1, P.tile_h - y0));
+        const float wb = (float)min(min(x1 + 1, P.tile_w - x1), min(y1 + 1, P.tile_h - y1));
+        const float rws = recip_for<1>(__fadd_rn(wa, wb));
+#pragma unroll
+        for (int z = 0; z < ZB; ++z)
+            if (FULL || z < gn) {
+                float va = (float)ldg_s<T>(t0[z] + (int64_t)y0 * P.tile_pitch + x0);
+                if (FLAT) va = __fmul_rn(va, fa);
+                float o = va;
+                if constexpr (NREF == 2) {
+                    float vb = (float)ldg_s<T>(t1[z] + (int64_t)y1 * P.tile_pitch + x1);
+                    if (FLAT) vb = __fmul_rn(vb, fb);
+                    o = __fmul_rn(__fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb)), rws);
+                }
+                stg_s<float>(cplane[z] + doff + p, o);
+            }
     }
 }
 
