@@ -26,7 +26,7 @@ def test_arena_is_classified_balanced_and_aliases_like_plain_memory():
     # 256 MiB chosen from up to 768 MiB of candidates: 8 MiB slices, 32 MiB probe units (the production sizes are 64 / 512 MiB)
     arena = native.DeviceArena(256 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=768 * MiB)
     info = arena.info
-    # candidates are taken chunk by chunk until the three largest classes each hold a third of the arena, 768 MiB at most
+    # candidates are taken chunk by chunk until the two largest classes hold half of the arena each (or three a third each), 768 MiB at most
     assert info['bytes'] == 256 * MiB == arena.nbytes and info['n_slices'] == 32 and 32 <= info['n_candidates'] <= 96
     assert 1 <= info['n_classes'] <= native.SQ_ARENA_MAX_CLASSES
     assert sum(info['class_slices']) == 32 and sum(info['class_candidates']) == info['n_candidates']
@@ -228,3 +228,23 @@ def test_an_address_that_was_mapped_is_never_mapped_again():
         assert (host == 0x01010101 * (k + 1)).all(), f'arena {k}: the copy read something else than the kernel wrote'
         del t
         arena.close()
+
+
+def test_two_classes_flag_maps_the_two_largest_classes_only():
+    """SQ_ARENA_TWO_CLASSES (the measurement aid behind the arena's stop rule -- two halves write as fast as three thirds,
+    profiles/r04_exp_arena_two_classes.log): when the two largest classes can fill the arena, no slice of another class is mapped;
+    the memory is as usable as any arena's."""
+    torch = _torch()
+    dev = torch.device('cuda:0')
+    arena = native.DeviceArena(256 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=768 * MiB, two_classes=True)
+    info = arena.info
+    assert sum(info['class_slices']) == 32
+    by_size = sorted(range(len(info['class_candidates'])), key=lambda c: -info['class_candidates'][c])
+    if len(by_size) > 2 and info['class_candidates'][by_size[0]] + info['class_candidates'][by_size[1]] >= 32:
+        assert all(info['class_slices'][c] == 0 for c in by_size[2:]), info
+    t = arena.take(arena.nbytes).view(torch.int32)
+    t.fill_(0x1234567)
+    torch.cuda.synchronize()
+    assert bool((t.cpu() == 0x1234567).all())
+    del t
+    arena.close()
