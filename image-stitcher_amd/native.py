@@ -435,7 +435,9 @@ class DeviceArena:
     round-robin into one virtual range, so a canvas carved from it is fast wherever it starts.
 
     ``take(nbytes)`` bump-allocates (512-byte aligned) and returns a uint8 tensor aliasing the range; ``reset()`` starts
-    over (the caller makes sure nothing uses the old tensors any more); ``close()`` unmaps and releases everything."""
+    over (the caller makes sure nothing uses the old tensors any more); ``close()`` unmaps and releases everything.
+    ``natural_order`` (no probe, slices as they come) and ``two_classes`` (the two largest classes only) are the controls of
+    A/B measurements."""
 
     def __init__(self, nbytes: int, device=None, slice_bytes: int = 0, unit_bytes: int = 0, natural_order: bool = False, stream=None,
                  candidate_bytes: Optional[int] = None, two_classes: bool = False):
@@ -448,8 +450,9 @@ class DeviceArena:
         with torch.cuda.device(self.device):
             if candidate_bytes is None:
                 # memory comes in runs of tens of GiB of one class: the call may take what is free (but for a reserve), chunk by
-                # chunk, until every class holds a third of the arena, and gives the rest back (create the arena FIRST, while
-                # the card is empty: it then takes 1.5-2.5 times its size for ~25 ms per GiB)
+                # chunk, until two classes hold half of the arena each (or three a third each), and gives the rest back (create
+                # the arena FIRST, while the card is empty: it then takes 1.25-2 times its size; the driver clears what it hands
+                # out and what it takes back -- 1-5 s for 80 GiB, once per process)
                 free = torch.cuda.mem_get_info(self.device)[0]
                 candidate_bytes = max(int(nbytes), min(8 * int(nbytes), free - (6 << 30)))
             self._h = L.sq_arena_create(int(nbytes), int(candidate_bytes), int(slice_bytes), int(unit_bytes),
