@@ -39,3 +39,29 @@ def test_no_spill_code_inside_the_kernels_loops():
     allowed = {'fuse_feather_zg_kernel<1, true, unsigned short>': 2}
     over = [(f, k, n) for f, k, n in found if n > max([v for name, v in allowed.items() if name in k] or [0])]
     assert not over, over
+
+
+def test_spill_scan_tells_prologue_from_loop(tmp_path):
+    """The scan itself, on a hand-written listing: spill code before the first loop and behind the last one is not counted, spill
+    code between a label and a later branch back to it is -- nested loops once."""
+    lst = tmp_path / 'k.s'
+    lst.write_text('''
+_Z1kv:
+	scratch_store_dword off, v1, off ; 4-byte Folded Spill
+.LBB0_1:
+	v_add_u32_e32 v0, 1, v0
+	scratch_load_dword v1, off, off ; 4-byte Folded Reload
+.LBB0_2:
+	scratch_store_dword off, v2, off offset:4 ; 4-byte Folded Spill
+	s_cbranch_vccnz .LBB0_2
+	s_cbranch_scc1 .LBB0_1
+	scratch_load_dword v2, off, off offset:4 ; 4-byte Folded Reload
+	s_endpgm
+_Z2k2v:
+	scratch_store_dword off, v1, off ; 4-byte Folded Spill
+	s_cbranch_scc1 .LBB1_9
+	scratch_load_dword v1, off, off ; 4-byte Folded Reload
+.LBB1_9:
+	s_endpgm
+''')
+    assert _scan_module().scan_spills(str(lst)) == {'_Z1kv': 2}
