@@ -429,7 +429,7 @@ class _RawDeviceMemory:
 
 class DeviceArena:
     """Device memory whose every stretch lies over all memory classes of the card (sq_arena_create, csrc/arena.hip): the
-    home of fusion canvases.  An MI355X's memory falls into three classes of a third of the card each; the fusion kernel's
+    home of fusion canvases.  An MI355X's memory falls into a few classes of tens of GiB each (thirds of the card where it was scanned); the fusion kernel's
     row-segment writes run at 0.55 of the HBM peak inside one class and at 0.73-0.76 spread over them, and a plain
     allocation gets runs of tens of GiB of ONE class.  The arena takes physical slices, measures their classes and maps them
     round-robin into one virtual range, so a canvas carved from it is fast wherever it starts.

@@ -157,7 +157,7 @@ int sq_fuse_planes(const sq_fuse_args *args, void *stream);
 /* ------------------------------------------------------------------------------------------
  * Canvas memory.  Replaces the allocation behind Stitcher.init_output (stitcher.py:356-362: the reference's canvas is a
  * lazy dask array; here it is device memory the fusion kernel writes once).  WHERE that memory lies decides how fast the
- * kernel can write it: MI355X device memory falls into three classes of a third of the card each, a row-segment write
+ * kernel can write it: MI355X device memory falls into a few classes of tens of GiB each (thirds of the card where it was scanned), a row-segment write
  * stream confined to one class runs at 0.55 of the HBM peak and at 0.73-0.76 when spread over the classes, and hipMalloc
  * hands out runs of tens of GiB of one class (csrc/arena.hip).  sq_arena_create takes `bytes` of device
  * memory in physical slices (hipMemCreate), measures which class every 512 MiB unit of them lies in (a pair-fill probe,
