@@ -198,13 +198,18 @@ def pcc_vectors():
               # 4410 = 2 3^2 5 7^2, 9720 = 2^3 3^5 5 = the longest line at all), a 9568 x 6380 sensor's crops
               # (4784 = 2^4 13 23 and 3190 = 2 5 11 29: Bluestein through 9600 and 6400 points), and the longest
               # Bluestein lines (4859 = 43 * 113 and 4858 = 2 * 7 * 347, both through 9720 points)
-              (6000, 300), (300, 6000), (4784, 60), (60, 3190), (4410, 52), (40, 9720), (4859, 34), (44, 4858)]
+              (6000, 300), (300, 6000), (4784, 60), (60, 3190), (4410, 52), (40, 9720), (4859, 34), (44, 4858),
+              # round 4: lines that do not fit the LDS (transformed in the workspace): a prime just past the limit (4861, Bluestein
+              # through >= 9721 points), 4862 = 2 11 13 17, a prime sensor side (9733), smooth lengths transformed directly
+              # (10000 = 2^4 5^4, 16384), 9728 = 2^9 19
+              (16, 4861), (4862, 12), (9733, 6), (10, 10000), (16384, 6), (9728, 8)]
     for i, (n0, n1) in enumerate(shapes):
         seed = 4242 + i
         dy, dx = [(3, -2), (-4, 5), (0, 0), (7, 1), (-1, -6), (2, 2), (5, -3), (-2, 4),
                   (4, -3), (-5, 6), (12, -11), (-9, 14), (1, -13),
                   (6, -9), (-7, 11), (13, 3), (-15, -4), (9, 16), (-3, -12),
-                  (11, -6), (-8, 14), (5, 9), (-12, -7), (15, -2), (-4, 10), (7, -15), (-10, 3)][i]
+                  (11, -6), (-8, 14), (5, 9), (-12, -7), (15, -2), (-4, 10), (7, -15), (-10, 3),
+                  (3, -14), (-11, 2), (9, 1), (-2, 13), (-14, -1), (6, 2)][i]
         big = synth.scene_patch(seed, 100, 100, n0 + 32, n1 + 32)      # 16-px margin: |planted| <= 16
         ref = big[16:16 + n0, 16:16 + n1]
         mov = big[16 - dy:16 - dy + n0, 16 - dx:16 - dx + n1] + synth.noise_patch(seed + 1, n0, n1, 150)
