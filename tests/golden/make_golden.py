@@ -360,6 +360,16 @@ def more_cases():
              use_registration=False)
 
 
+def long_line_cases():
+    """Round 4: a sensor whose registration crops do not fit the LDS as FFT lines -- 96 x 19466 tiles: the vertical pair's crop is
+    (overlap) x 9734 = 2 * 4867 (a Bluestein line of >= 19467 points, transformed in the workspace by the device path); the
+    reference (pocketfft) takes any length (stitcher.py:503-510, 516-523)."""
+    G = synth.GridSpec
+    run_case('reg_long_lines', G(rows=2, cols=2, tile_h=96, tile_w=19466, ov_y=28, ov_x=310, seed=3100),
+             use_registration=True, keep_canvas=False,
+             windows=[(0, 0, 60, 19100, 48, 96), (0, 0, 0, 0, 16, 128), (0, 0, 120, 38000, 40, 80)])
+
+
 def forced_cases():
     """The reference's integer geometry (canvas size, placement, crops, clip: stitcher.py:298-354, 563-605,
     639-689) driven with dictated shifts of every sign combination -- including ones no registration of real
@@ -381,6 +391,8 @@ def forced_cases():
 def main():
     if sys.argv[1:] == ['forced']:
         return forced_cases()
+    if sys.argv[1:] == ['long']:
+        return long_line_cases()
     if sys.argv[1:] == ['more']:
         return more_cases()
     if sys.argv[1:] == ['normalize']:
