@@ -14,8 +14,9 @@
 //      one reserved virtual range (hipMemAddressReserve / hipMemMap);
 //   2. classify UNITS (512 MiB of consecutively created slices: physical memory is handed out in long runs) as they come: a
 //      unit joins the first class whose reference unit it collides with -- the pair fills less than 1.17 times faster than the
-//      reference alone -- or becomes the reference of a new class; stop taking memory once the two largest classes each
-//      hold half of the arena or the three largest a third each (or the caller's cap is reached, or the card is full);
+//      reference alone -- or becomes the reference of a new class; stop taking memory once the three largest classes each
+//      hold a third of the arena -- or, after 2.5 x the arena, the two largest half of it each -- (or the caller's cap is
+//      reached, or the card is full);
 //   3. choose the arena's slices round-robin over the classes, give the others back, and map the chosen ones in that order.
 // Every 200 MB of such an arena then holds all classes, wherever a plane starts and however many planes a launch writes:
 // one plane alone fills at 0.72-0.75, five consecutive planes at 0.75-0.76, the fusion kernel's structure goes from
@@ -286,15 +287,16 @@ extern "C" sq_arena *sq_arena_create(int64_t bytes, int64_t candidate_bytes, int
         class_slices_taken.assign(ref_unit.size(), 0);
         for (size_t u = 0; u < nunits; ++u) class_slices_taken[cls[u]] += spu;
     };
-    // enough taken: a third of the arena in each of the three largest classes, or half of it in each of the two largest -- two
-    // halves write as fast as three thirds or a five-class mix (the real kernel, one process: 0.717 against 0.710,
-    // profiles/r04_exp_arena_two_classes.log; a card that shows two classes only: 0.724 on config 3), and the driver bills
-    // every candidate slice (it clears memory it hands out and memory it takes back)
-    auto balanced = [&](size_t) {
+    // enough taken: a third of the arena in each of the three largest classes -- or, once 2.5 x the arena has been looked at, half
+    // of it in each of the two largest (some cards show two classes only; going on to the end of such a card cost 8.6 s).  Three
+    // thirds are worth waiting for: over the round's bench runs arenas of three or more classes gave 0.725-0.736 on config 3
+    // and 0.732-0.741 on the headline job's batches, arenas of two halves 0.721-0.726 and 0.711-0.730 (profiles/r04_bench_cfg3_v36
+    // ... v44.json; the one-process A/B on 20 planes, profiles/r04_exp_arena_two_classes.log, had seen no difference).
+    auto balanced = [&](size_t have_now) {
         std::vector<size_t> c(class_slices_taken);
         std::sort(c.rbegin(), c.rend());
         if (c.size() >= 3 && c[2] >= (n + 2) / 3) return true;
-        return c.size() >= 2 && c[1] >= (n + 1) / 2;
+        return c.size() >= 2 && 2 * have_now >= 5 * n && c[1] >= (n + 1) / 2;
     };
     size_t have = 0;
     bool full = false;

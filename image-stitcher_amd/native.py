@@ -450,9 +450,9 @@ class DeviceArena:
         with torch.cuda.device(self.device):
             if candidate_bytes is None:
                 # memory comes in runs of tens of GiB of one class: the call may take what is free (but for a reserve), chunk by
-                # chunk, until two classes hold half of the arena each (or three a third each), and gives the rest back (create
-                # the arena FIRST, while the card is empty: it then takes 1.25-2 times its size; the driver clears what it hands
-                # out and what it takes back -- 1-5 s for 80 GiB, once per process)
+                # chunk, until three classes hold a third of the arena each (after 2.5 x the arena: two classes half each), and
+                # gives the rest back (create the arena FIRST, while the card is empty: it then takes 1.5-2.5 times its size; the
+                # driver clears what it hands out and what it takes back -- 0.5-6 s for 80 GiB, once per process)
                 free = torch.cuda.mem_get_info(self.device)[0]
                 candidate_bytes = max(int(nbytes), min(8 * int(nbytes), free - (6 << 30)))
             self._h = L.sq_arena_create(int(nbytes), int(candidate_bytes), int(slice_bytes), int(unit_bytes),

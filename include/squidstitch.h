@@ -167,10 +167,11 @@ int sq_fuse_planes(const sq_fuse_args *args, void *stream);
  * planes on 128-byte lines, see sq_fuse_args) and destroys it when no kernel uses it any more.  Synchronises `stream`.
  * Tiles, gains and plans may live anywhere: reads do not depend on the class.
  *   candidate_bytes: the most memory the call may take while it looks for a balanced arena (0 = bytes: whatever comes).  Memory
- *       comes in runs of tens of GiB of one class, so candidates are taken chunk by chunk and classified until the two largest
- *       classes hold half of `bytes` each (or the three largest a third each); the rest is given back -- and is back -- before
- *       the call returns.  Pass what is free (less a reserve) and create the arena FIRST, while the card is still empty:
- *       typically 1.25-2 x bytes are taken; the driver clears every slice it hands out and takes back (1-5 s for 80 GiB).
+ *       comes in runs of tens of GiB of one class, so candidates are taken chunk by chunk and classified until the three largest
+ *       classes hold a third of `bytes` each (or, after 2.5 x bytes, the two largest half each); the rest is given back -- and
+ *       is back -- before the call returns.  Pass what is free (less a reserve) and create the arena FIRST, while the card is
+ *       still empty: typically 1.5-2.5 x bytes are taken; the driver clears every slice it hands out and takes back (0.5-6 s
+ *       for 80 GiB).
  *   slice_bytes: 0 = 64 MiB (a multiple of 2 MiB);  unit_bytes: 0 = 512 MiB (a multiple of the slice, >= 16 MiB)
  *   flags: SQ_ARENA_NATURAL_ORDER = skip the probe and keep the slices in creation order (the control of A/B runs);
  *          SQ_ARENA_TWO_CLASSES = map slices of the two largest classes only (a measurement aid: two halves against three thirds)

@@ -26,7 +26,7 @@ def test_arena_is_classified_balanced_and_aliases_like_plain_memory():
     # 256 MiB chosen from up to 768 MiB of candidates: 8 MiB slices, 32 MiB probe units (the production sizes are 64 / 512 MiB)
     arena = native.DeviceArena(256 * MiB, dev, slice_bytes=8 * MiB, unit_bytes=32 * MiB, candidate_bytes=768 * MiB)
     info = arena.info
-    # candidates are taken chunk by chunk until the two largest classes hold half of the arena each (or three a third each), 768 MiB at most
+    # candidates are taken chunk by chunk until three classes hold a third of the arena each (after 2.5 x: two classes half each), 768 MiB at most
     assert info['bytes'] == 256 * MiB == arena.nbytes and info['n_slices'] == 32 and 32 <= info['n_candidates'] <= 96
     assert 1 <= info['n_classes'] <= native.SQ_ARENA_MAX_CLASSES
     assert sum(info['class_slices']) == 32 and sum(info['class_candidates']) == info['n_candidates']

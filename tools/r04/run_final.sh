@@ -5,11 +5,11 @@ timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/gputest_final.log 2>
 tail -2 $O/gputest_final.log
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_final.log 2>&1 || { echo smoke failed; tail -20 $O/smoke_final.log; exit 1; }
 tail -1 $O/smoke_final.log
-timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_v44.out 2> $O/bench_v44.err || { echo bench failed; tail -30 $O/bench_v44.err; exit 1; }
-grep "^{" $O/bench_v44.out | tail -1 > $O/bench_v44.json
+timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_v45.out 2> $O/bench_v45.err || { echo bench failed; tail -30 $O/bench_v45.err; exit 1; }
+grep "^{" $O/bench_v45.out | tail -1 > $O/bench_v45.json
 python3 - <<'PY'
 import json
-d = json.load(open('gpurun_out/r4/bench_v44.json'))
+d = json.load(open('gpurun_out/r4/bench_v45.json'))
 print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'], 'launch', d['roofline']['launch_ms'], 'traffic', d['roofline']['traffic'])
 print('arena', d['config']['memory']['canvas_arena']['class_slices'], d['config']['memory']['canvas_arena']['create_ms'])
 print('parity', d['parity']['fused_mismatched_voxels'], d['parity']['shift_rmse_px'])
