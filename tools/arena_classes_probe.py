@@ -21,7 +21,8 @@ arenas = {'all classes': native.DeviceArena(need, dev), 'two classes': native.De
 for k, a in arenas.items():
     print(f'{k}: class_slices {a.info["class_slices"]} of candidates {a.info["class_candidates"]}, {a.info["create_ms"]:.0f} ms', flush=True)
 canvases = {k: native.empty_canvas(P, hc, wc, torch.uint16, dev, arena=a) for k, a in arenas.items()}
-canvases['plain allocation'] = native.empty_canvas(P, hc, wc, torch.uint16, dev)
+if P <= 20:      # (more planes: the card has no room for a third canvas beside the tiles)
+    canvases['plain allocation'] = native.empty_canvas(P, hc, wc, torch.uint16, dev)
 tiles = torch.empty((P, g * g, T, T), dtype=torch.uint16, device=dev)
 for p in range(P):
     native.synth_tiles(bench.plane_desc(spec, g, p // Z, p % Z), T, T, spec.noise, 'uint16', dev, out=tiles[p])
